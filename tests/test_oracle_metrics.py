@@ -1,0 +1,139 @@
+"""The metric oracle (oracle/metrics.py) against the golden vectors that the reference's own
+functions produced (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import metrics as OM
+from oracle import search as OS
+
+SETS = ["covidx300_d64", "mod3_1000_d32", "rand_257_d16"]
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    with open(os.path.join(golden_dir, "known_answers.json")) as fh:
+        return json.load(fh)
+
+
+def test_known_answers(known):
+    t = known["compute_map_tiny"]
+    mAP, aps, pr, prs = OM.compute_map(np.array(t["ranks"]), np.array(t["gnd"]), t["kappas"])
+    assert mAP == pytest.approx(t["mAP"], abs=1e-15)
+    np.testing.assert_allclose(aps, t["aps"], atol=1e-15)
+    np.testing.assert_allclose(pr, t["pr"], atol=1e-15)
+    np.testing.assert_allclose(prs, t["prs"], atol=1e-15)
+    for c in known["compute_ap"]:
+        assert OM.compute_ap(c["ranks"], c["nres"]) == pytest.approx(c["ap"], abs=1e-15)
+    for c in known["precision_at_k"]:
+        assert OM.precision_at_k(c["rel"], c["k"]) == pytest.approx(c["out"], abs=1e-15)
+    for c in known["recall_at_k"]:
+        assert OM.recall_at_k(c["rel"], c["tp"], c["k"]) == pytest.approx(c["out"], abs=1e-15)
+    for c in known["jaccard_score"]:
+        assert OM.jaccard_score(c["a"], c["b"]) == pytest.approx(c["out"], abs=1e-15)
+    for c in known["majority_vote"]:
+        assert OM.majority_vote(c["labels"]) == c["out"]
+    # values quoted in SURVEY.md section 8c
+    assert t["mAP"] == pytest.approx(0.5833333333333334)
+    assert known["seed0_12x8"]["acc"] == [25.0, 75.0, 100.0]
+    assert known["seed0_12x8"]["mAP"] == pytest.approx(0.30761859668109665)
+
+
+def _rank(z, metric):
+    emb = z["embeds"]
+    m = OS.METRIC_IP if metric == "cosine" else OS.METRIC_NEG_L2
+    return OS.rank_all(emb, emb, metric=m, exclude=np.arange(len(emb)))
+
+
+@pytest.mark.parametrize("name", SETS)
+@pytest.mark.parametrize("metric", ["cdist", "cosine"])
+def test_tail_against_reference_outputs(golden_dir, name, metric):
+    """Two checks per golden set:
+    (1) metric functions alone: fed the reference's OWN fp32 ranking they must reproduce the
+        reference's outputs to 1e-12 (pins compute_map / retrieval_accuracy / majority vote);
+    (2) whole tail from the fp64 search oracle: the reference's fp32 cdist/argsort swaps
+        near-ties, so the comparison allows -- and prints -- those queries.
+    """
+    z = np.load(os.path.join(golden_dir, f"tail_{name}.npz"))
+    labels = z["labels"]
+    n = len(labels)
+    if f"{metric}_ranks_ref_fp32" in z.files:
+        ref = z[f"{metric}_ranks_ref_fp32"].astype(np.int64)          # [db, nq] as the reference has it
+        mAP, aps, pr, prs = OM.compute_map(ref, labels, [1, 5, 10])
+        assert mAP == pytest.approx(float(z[f"{metric}_mAP"]), abs=1e-12)
+        np.testing.assert_allclose(aps, z[f"{metric}_aps"], atol=1e-12)
+        np.testing.assert_allclose(pr, z[f"{metric}_pr"], atol=1e-12)
+        np.testing.assert_allclose(prs, z[f"{metric}_prs"], atol=1e-12)
+        np.testing.assert_allclose(OM.retrieval_accuracy(ref.T[:, :10], labels, (1, 5, 10)),
+                                   z[f"{metric}_acc"], atol=1e-5)
+        cls = OM.compute_classification_metrics(labels, ref.T, (1, 5, 10, 15, 20))
+        for k in (1, 5, 10, 15, 20):
+            np.testing.assert_allclose(cls[k], z[f"{metric}_cls_k{k}"], atol=1e-9)
+
+    ranks = _rank(z, metric)                       # [nq, n], fp64 scores, ties -> lowest id
+    flips = 0
+    if f"{metric}_ranks_ref_fp32" in z.files:
+        flips = int(np.sum(np.any(ref.T[:, :20] != ranks[:, :20], axis=1)))
+        print(f"{name}/{metric}: reference fp32 top-20 order differs from the fp64 oracle on "
+              f"{flips}/{n} queries (fp32 near-ties)")
+        assert flips <= max(2, n // 50)
+    slack = max(flips, n // 100) + 1               # queries that may move by one rank
+    mAP, aps, pr, prs = OM.compute_map(ranks.T, labels, [1, 5, 10])
+    assert abs(mAP - float(z[f"{metric}_mAP"])) <= slack / n * 0.05 + 1e-9
+    assert np.all(np.abs(pr - z[f"{metric}_pr"]) <= slack / n + 1e-9)
+    acc = OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10))
+    assert np.all(np.abs(np.asarray(acc) - z[f"{metric}_acc"]) <= 100.0 * slack / n + 1e-4)
+    assert np.count_nonzero(np.abs(aps - z[f"{metric}_aps"]) > 1e-9) <= slack * 4
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_fusion_metrics(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"tail_{name}.npz"))
+    emb = OM.l2_normalize_np(z["embeds"].astype(np.float32))
+    n = len(emb)
+    # fusion_eval ranks by fp32 cosine with the diagonal at -inf; self is then dropped by path
+    ranks = OS.rank_all(emb, emb, metric=OS.METRIC_IP, exclude=np.arange(n))
+    out = OM.fusion_metrics_from_ranks(ranks, [str(x) for x in z["labels"]],
+                                       [f"img_{i}.png" for i in range(n)], (1, 5, 10))
+    ref = dict(zip(z["fusion_keys"].tolist(), z["fusion_vals"].tolist()))
+    for k, v in ref.items():
+        assert out[k] == pytest.approx(v, abs=1e-3 if k == "mAP" else 1e-9), k
+
+
+def test_multilabel_and_nih(golden_dir):
+    z = np.load(os.path.join(golden_dir, "multilabel_120.npz"))
+    emb = z["embeds"]
+    ranks = OS.rank_all(emb, emb, metric=OS.METRIC_IP, exclude=np.arange(len(emb)))
+    assert OM.compute_map_multilabel(ranks, z["labels"], 0.5) == pytest.approx(float(z["map_t05"]), abs=1e-5)
+    assert OM.compute_map_multilabel(ranks, z["labels"], 0.4) == pytest.approx(float(z["map_t04"]), abs=1e-5)
+    with open(os.path.join(golden_dir, "nih_results_40.json")) as fh:
+        j = json.load(fh)
+    out = OM.evaluate_results(j["items"], j["threshold"], j["ks"])
+    for k, v in j["metrics"].items():
+        assert out[k] == pytest.approx(v, abs=1e-9), k
+
+
+def test_fuse(golden_dir):
+    z = np.load(os.path.join(golden_dir, "fusion_fuse.npz"))
+    np.testing.assert_allclose(OM.l2_normalize_np(z["a"]), z["l2"], atol=1e-7)
+    np.testing.assert_allclose(OM.concat_fusion(z["a"], z["c"]), z["concat"], atol=1e-7)
+    np.testing.assert_allclose(OM.weighted_sum_fusion(z["a"], z["b"], 0.3), z["wsum03"], atol=1e-7)
+    assert OM.weighted_sum_fusion(z["a"], z["c"], 0.5) is None
+    assert "dimension_mismatch" in str(z["wsum_mismatch_reason"])
+
+
+def test_evaluate_npz_fields(golden_dir):
+    """The .npz the reference's evaluate() writes (test.py:1122-1126): field inventory + values."""
+    z = np.load(os.path.join(golden_dir, "evaluate_covidx300_d64.npz"))
+    need = {"embeds", "labels", "dists", "kappas", "acc", "mAP", "pr", "classification_k_values"} | {
+        f"classification_k{k}" for k in (1, 5, 10, 15, 20)}
+    assert need <= set(z.files)
+    emb, labels = z["embeds"], z["labels"]
+    ranks = OS.rank_all(emb, emb, metric=OS.METRIC_NEG_L2, exclude=np.arange(len(emb)))
+    mAP, _, pr, _ = OM.compute_map(ranks.T, labels, [1, 5, 10])
+    assert mAP == pytest.approx(float(z["mAP"]), abs=2e-4)         # fp32 near-tie flips, see above
+    np.testing.assert_allclose(pr, z["pr"], atol=4 / 300)
+    np.testing.assert_allclose(OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10)), z["acc"], atol=1.0)
+    assert np.all(np.isposinf(np.diag(z["dists"])))          # dists saved as +L2 with +inf diagonal
