@@ -1,0 +1,385 @@
+// k_exact.hip -- the exact tier: fp64 score tiles, per-row top-k selection, full ranking,
+// multi-shard top-k merge.  Every returned score comes from lane_tree_score() so that it is
+// bit-identical to oracle/search_ref.c.
+//
+// Reference behaviour replaced (paths into /root/reference):
+//   -torch.cdist(e, e) / e @ e.t()                 test.py:1080, test_nonclip.py:151
+//   fill_diagonal_(-inf)                            test.py:1081   -> exclude ids
+//   output.topk(maxk, 1, True, True)                test.py:44
+//   torch.argsort(dists, dim=0, descending=True)    test.py:1090,179  -> launch_rank_rows
+#include "mirx_kernels.h"
+
+#include <math.h>
+
+namespace mirx {
+
+namespace {
+
+constexpr int64_t ID_LAST = INT64_MAX;   // sentinel id: sorts after every real id
+
+// ---- fp64 score tile ----------------------------------------------------------------------
+// Workgroup = 4 waves; QT queries live in registers as doubles; each wave walks 64 gallery
+// rows, one coalesced 16-B-per-lane load per chunk, and keeps row i's score in lane i so the
+// 64 results leave as one coalesced store per query.
+template <int METRIC, int CPL, int QT>
+__global__ __launch_bounds__(256) void k_scores_f64(const float *__restrict__ q32p,
+                                                    const int32_t *__restrict__ qlist, int nq,
+                                                    const float *__restrict__ g32, int64_t n,
+                                                    int dimp, double *__restrict__ out, int64_t ld) {
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int nchunk = dimp >> 2;
+    const int qbase = blockIdx.y * QT;
+    double qr[QT][CPL][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int pos = qbase + t;
+        const int64_t qi = pos < nq ? (qlist ? (int64_t)qlist[pos] : (int64_t)pos) : -1;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int chunk = lane + WAVE * c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi >= 0 && chunk < nchunk) v = *reinterpret_cast<const float4 *>(q32p + qi * dimp + 4 * chunk);
+            qr[t][c][0] = v.x; qr[t][c][1] = v.y; qr[t][c][2] = v.z; qr[t][c][3] = v.w;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    if (r0 >= n) return;
+    double keep[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) keep[t] = 0.0;
+    const int rows = (int)((n - r0) < 64 ? (n - r0) : 64);
+    for (int i = 0; i < rows; ++i) {
+        const float *g = g32 + (r0 + i) * dimp;
+        float4 gv[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int chunk = lane + WAVE * c;
+            gv[c] = chunk < nchunk ? *reinterpret_cast<const float4 *>(g + 4 * chunk)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const double b[4] = {(double)gv[c].x, (double)gv[c].y, (double)gv[c].z, (double)gv[c].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (METRIC == 0) {
+                        acc = fma(qr[t][c][e], b[e], acc);
+                    } else {
+                        const double d = qr[t][c][e] - b[e];
+                        acc = fma(d, d, acc);
+                    }
+                }
+            }
+            acc = wave_butterfly_sum(acc);
+            if (lane == i) keep[t] = METRIC == 0 ? acc : -acc;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int pos = qbase + t;
+        if (pos < nq && lane < rows) out[(int64_t)pos * ld + r0 + lane] = keep[t];
+    }
+}
+
+// Fallback for very wide rows (dimp > 2048): one query per workgroup row, q from memory.
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_scores_f64_wide(const float *__restrict__ q32p,
+                                                         const int32_t *__restrict__ qlist, int nq,
+                                                         const float *__restrict__ g32, int64_t n,
+                                                         int dimp, double *__restrict__ out,
+                                                         int64_t ld) {
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int pos = blockIdx.y;
+    const int64_t qi = qlist ? (int64_t)qlist[pos] : (int64_t)pos;
+    const int64_t r0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    for (int i = 0; i < 64 && r0 + i < n; ++i) {
+        const double s = lane_tree_score<METRIC>(q32p + qi * dimp, g32 + (r0 + i) * dimp, dimp);
+        if (lane == 0) out[(int64_t)pos * ld + r0 + i] = s;
+    }
+}
+
+// ---- bitonic network on Hit records in LDS ---------------------------------------------------
+// Sorts a[0..m) (m a power of two) into "before" order (best first) with 256 threads.
+__device__ inline void bitonic_sort_lds(Hit *a, int m) {
+    for (int size = 2; size <= m; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (m >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (stride - 1));
+                const int j = i + stride;
+                const bool best_first = (i & size) == 0;
+                const Hit x = a[i], y = a[j];
+                const bool y_before_x = hit_before(y.s, y.id, x.s, x.id);
+                if (y_before_x == best_first) { a[i] = y; a[j] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ inline int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+__device__ inline float reported_value(double rank_score, int metric) {
+    if (rank_score == -INFINITY) return -INFINITY;
+    return metric == MIRX_METRIC_IP ? (float)rank_score : (float)(-sqrt(fmax(-rank_score, 0.0)));
+}
+
+// ---- streaming top-k of one score row ---------------------------------------------------------
+constexpr int TK_TOTAL = 2048;   // LDS records: kp sorted + (TK_TOTAL - kp) pending, kp <= 1024
+
+__global__ __launch_bounds__(256) void k_row_topk(const double *__restrict__ scores, int64_t ld,
+                                                  int64_t n, const int64_t *__restrict__ ids,
+                                                  const int32_t *__restrict__ qlist,
+                                                  const int64_t *__restrict__ exclude, int k, int kp,
+                                                  int metric, double *__restrict__ out_f64,
+                                                  int64_t *__restrict__ out_ids,
+                                                  float *__restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Hit *best = reinterpret_cast<Hit *>(smem);                       // [kp] sorted + [round] pending
+    int *pend_cnt = reinterpret_cast<int *>(smem + (size_t)TK_TOTAL * sizeof(Hit));
+    const int round = TK_TOTAL - kp;
+    const int pos = blockIdx.x;
+    const int64_t qi = qlist ? (int64_t)qlist[pos] : (int64_t)pos;
+    const int64_t ex = exclude ? exclude[qi] : -1;
+    const double *row = scores + (int64_t)pos * ld;
+    for (int i = threadIdx.x; i < kp; i += 256) { best[i].s = -INFINITY; best[i].id = ID_LAST; }
+    for (int64_t base = 0; base < n; base += round) {
+        if (threadIdx.x == 0) *pend_cnt = 0;
+        __syncthreads();
+        const Hit kth = best[k - 1];
+        for (int e = threadIdx.x; e < round; e += 256) {
+            const int64_t j = base + e;
+            if (j < n) {
+                const double s = row[j];
+                const int64_t id = ids ? ids[j] : j;
+                if (id != ex && hit_before(s, id, kth.s, kth.id)) {
+                    const int p = atomicAdd(pend_cnt, 1);
+                    best[kp + p].s = s;
+                    best[kp + p].id = id;
+                }
+            }
+        }
+        __syncthreads();
+        const int c = *pend_cnt;
+        if (c > 0) {
+            const int m = pow2_ceil(kp + c);
+            for (int i = kp + c + threadIdx.x; i < m; i += 256) { best[i].s = -INFINITY; best[i].id = ID_LAST; }
+            bitonic_sort_lds(best, m);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < k; r += 256) {
+        const Hit h = best[r];
+        const bool empty = h.id == ID_LAST;
+        out_f64[qi * k + r] = empty ? -INFINITY : h.s;
+        out_ids[qi * k + r] = empty ? -1 : h.id;
+        if (out_val) out_val[qi * k + r] = empty ? -INFINITY : reported_value(h.s, metric);
+    }
+}
+
+// ---- full ranking: global bitonic sort of padded rows -----------------------------------------
+constexpr int RK_BLOCK = 2048;
+
+__global__ __launch_bounds__(256) void k_rank_build(const double *__restrict__ scores, int64_t ld,
+                                                    int64_t n, const int64_t *__restrict__ ids,
+                                                    const int64_t *__restrict__ exclude,
+                                                    Hit *__restrict__ work, int64_t np2) {
+    const int64_t qi = blockIdx.y;
+    const int64_t ex = exclude ? exclude[qi] : -1;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < np2; j += (int64_t)gridDim.x * 256) {
+        Hit h;
+        if (j < n) {
+            h.id = ids ? ids[j] : j;
+            h.s = (h.id == ex) ? -INFINITY : scores[qi * ld + j];
+        } else {
+            h.id = ID_LAST;
+            h.s = -INFINITY;
+        }
+        work[qi * np2 + j] = h;
+    }
+}
+
+// Runs every network step whose stride is < lb on one lb-element block held in LDS.
+// first_size: smallest `size` to run (2 for the initial local sort, else the current size).
+__global__ __launch_bounds__(256) void k_rank_local(Hit *__restrict__ work, int64_t np2, int lb,
+                                                    int first_size, int last_size) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Hit *a = reinterpret_cast<Hit *>(smem);
+    const int64_t qi = blockIdx.y;
+    const int64_t b0 = (int64_t)blockIdx.x * lb;          // local index of the block's first element
+    Hit *src = work + qi * np2 + b0;
+    for (int i = threadIdx.x; i < lb; i += 256) a[i] = src[i];
+    for (int64_t size = first_size; size <= last_size; size <<= 1) {
+        int stride0 = (int)((size >> 1) < lb ? (size >> 1) : (lb >> 1));
+        for (int stride = stride0; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (lb >> 1); t += 256) {
+                const int i = 2 * t - (t & (stride - 1));
+                const int j = i + stride;
+                const bool best_first = ((b0 + i) & size) == 0;
+                const Hit x = a[i], y = a[j];
+                const bool y_before_x = hit_before(y.s, y.id, x.s, x.id);
+                if (y_before_x == best_first) { a[i] = y; a[j] = x; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lb; i += 256) src[i] = a[i];
+}
+
+// One global compare-exchange step (stride >= lb).
+__global__ __launch_bounds__(256) void k_rank_global(Hit *__restrict__ work, int64_t np2, int64_t size,
+                                                     int64_t stride) {
+    const int64_t qi = blockIdx.y;
+    Hit *a = work + qi * np2;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < (np2 >> 1); t += (int64_t)gridDim.x * 256) {
+        const int64_t i = 2 * t - (t & (stride - 1));
+        const int64_t j = i + stride;
+        const bool best_first = (i & size) == 0;
+        const Hit x = a[i], y = a[j];
+        const bool y_before_x = hit_before(y.s, y.id, x.s, x.id);
+        if (y_before_x == best_first) { a[i] = y; a[j] = x; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rank_write(const Hit *__restrict__ work, int64_t np2, int64_t n,
+                                                    int metric, int64_t *__restrict__ out_ids,
+                                                    float *__restrict__ out_val) {
+    const int64_t qi = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+        const Hit h = work[qi * np2 + j];
+        out_ids[qi * n + j] = h.id;
+        if (out_val) out_val[qi * n + j] = reported_value(h.s, metric);
+    }
+}
+
+// ---- multi-shard merge ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_topk_merge(const double *__restrict__ in_scores,
+                                                    const int64_t *__restrict__ in_ids, int nshard,
+                                                    int64_t nq, int k, int metric,
+                                                    double *__restrict__ out_f64,
+                                                    float *__restrict__ out_val,
+                                                    int64_t *__restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Hit *a = reinterpret_cast<Hit *>(smem);
+    const int64_t qi = blockIdx.x;
+    const int total = nshard * k;
+    const int m = pow2_ceil(total);
+    for (int i = threadIdx.x; i < m; i += 256) {
+        Hit h;
+        h.s = -INFINITY;
+        h.id = ID_LAST;
+        if (i < total) {
+            const int sh = i / k, r = i % k;
+            const int64_t id = in_ids[((int64_t)sh * nq + qi) * k + r];
+            if (id >= 0) { h.id = id; h.s = in_scores[((int64_t)sh * nq + qi) * k + r]; }
+        }
+        a[i] = h;
+    }
+    bitonic_sort_lds(a, m);
+    for (int r = threadIdx.x; r < k; r += 256) {
+        const Hit h = a[r];
+        const bool empty = h.id == ID_LAST;
+        if (out_f64) out_f64[qi * k + r] = empty ? -INFINITY : h.s;
+        out_ids[qi * k + r] = empty ? -1 : h.id;
+        if (out_val) out_val[qi * k + r] = empty ? -INFINITY : reported_value(h.s, metric);
+    }
+}
+
+template <int METRIC>
+hipError_t launch_scores_t(const float *q32p, const int32_t *qlist, int nq, const float *g32, int64_t n,
+                           int dimp, double *out, int64_t ld, hipStream_t st) {
+    const unsigned gx = (unsigned)((n + 255) / 256);
+    if (dimp <= 256) {
+        hipLaunchKernelGGL((k_scores_f64<METRIC, 1, 4>), dim3(gx, (nq + 3) / 4), dim3(256), 0, st, q32p,
+                           qlist, nq, g32, n, dimp, out, ld);
+    } else if (dimp <= 512) {
+        hipLaunchKernelGGL((k_scores_f64<METRIC, 2, 4>), dim3(gx, (nq + 3) / 4), dim3(256), 0, st, q32p,
+                           qlist, nq, g32, n, dimp, out, ld);
+    } else if (dimp <= 1024) {
+        hipLaunchKernelGGL((k_scores_f64<METRIC, 4, 4>), dim3(gx, (nq + 3) / 4), dim3(256), 0, st, q32p,
+                           qlist, nq, g32, n, dimp, out, ld);
+    } else if (dimp <= 2048) {
+        hipLaunchKernelGGL((k_scores_f64<METRIC, 8, 2>), dim3(gx, (nq + 1) / 2), dim3(256), 0, st, q32p,
+                           qlist, nq, g32, n, dimp, out, ld);
+    } else {
+        hipLaunchKernelGGL((k_scores_f64_wide<METRIC>), dim3(gx, nq), dim3(256), 0, st, q32p, qlist, nq,
+                           g32, n, dimp, out, ld);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_scores_f64(const float *q32p, const int32_t *qlist, int nq, const float *g32,
+                             int64_t n, int dimp, int metric, double *out, int64_t ld,
+                             hipStream_t st) {
+    if (nq <= 0 || n <= 0) return hipSuccess;
+    return metric == MIRX_METRIC_IP ? launch_scores_t<0>(q32p, qlist, nq, g32, n, dimp, out, ld, st)
+                                    : launch_scores_t<1>(q32p, qlist, nq, g32, n, dimp, out, ld, st);
+}
+
+hipError_t launch_row_topk(const double *scores, int64_t ld, int64_t n, const int64_t *ids,
+                           const int32_t *qlist, int nq, const int64_t *exclude, int k, int metric,
+                           double *out_f64, int64_t *out_ids, float *out_val, hipStream_t st) {
+    if (nq <= 0) return hipSuccess;
+    int kp = 1;
+    while (kp < k) kp <<= 1;
+    if (kp > TK_TOTAL / 2) return hipErrorInvalidValue;
+    const size_t lds = (size_t)TK_TOTAL * sizeof(Hit) + 16;
+    hipLaunchKernelGGL(k_row_topk, dim3(nq), dim3(256), lds, st, scores, ld, n, ids, qlist, exclude, k,
+                       kp, metric, out_f64, out_ids, out_val);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_rows(const double *scores, int64_t ld, int64_t n, const int64_t *ids,
+                            const int64_t *exclude, int nq, Hit *work, int64_t np2, int metric,
+                            int64_t *out_ids, float *out_val, hipStream_t st) {
+    if (nq <= 0 || n <= 0) return hipSuccess;
+    const int lb = (int)(np2 < RK_BLOCK ? np2 : RK_BLOCK);
+    const unsigned gx_elem = (unsigned)((np2 + 255) / 256 < 1024 ? (np2 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_rank_build, dim3(gx_elem, nq), dim3(256), 0, st, scores, ld, n, ids, exclude,
+                       work, np2);
+    const size_t lds = (size_t)lb * sizeof(Hit);
+    const unsigned nblk = (unsigned)(np2 / lb);
+    // all steps with size <= lb
+    hipLaunchKernelGGL(k_rank_local, dim3(nblk, nq), dim3(256), lds, st, work, np2, lb, 2, lb);
+    for (int64_t size = (int64_t)lb * 2; size <= np2; size <<= 1) {
+        for (int64_t stride = size >> 1; stride >= lb; stride >>= 1) {
+            const unsigned gx = (unsigned)(((np2 >> 1) + 255) / 256 < 2048 ? ((np2 >> 1) + 255) / 256 : 2048);
+            hipLaunchKernelGGL(k_rank_global, dim3(gx, nq), dim3(256), 0, st, work, np2, size, stride);
+        }
+        hipLaunchKernelGGL(k_rank_local, dim3(nblk, nq), dim3(256), lds, st, work, np2, lb, (int)size,
+                           (int)size);
+    }
+    const unsigned gw = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_rank_write, dim3(gw, nq), dim3(256), 0, st, work, np2, n, metric, out_ids,
+                       out_val);
+    return hipGetLastError();
+}
+
+hipError_t launch_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, int64_t nq,
+                             int k, int metric, double *out_f64, float *out_val, int64_t *out_ids,
+                             hipStream_t st) {
+    if (nq <= 0) return hipSuccess;
+    int m = 1;
+    while (m < nshard * k) m <<= 1;
+    const size_t lds = (size_t)m * sizeof(Hit);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_topk_merge),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)nq), dim3(256), lds, st, in_scores, in_ids, nshard,
+                       nq, k, metric, out_f64, out_val, out_ids);
+    return hipGetLastError();
+}
+
+}  // namespace mirx

@@ -1,0 +1,173 @@
+// k_prep.hip -- streaming (HBM-bound) kernels: gallery ingest, query preparation,
+// L2 normalisation and the fused BN+ReLU+GAP+L2-norm embedding head.
+//
+// Reference behaviour replaced (paths into /root/reference):
+//   F.normalize(x, dim=1)                       model.py:83,116,493,634; milvus_retrieval.py:63
+//   norm5 -> relu -> AdaptiveAvgPool2d(1) -> flatten -> normalize      model.py:59-60,73-74,83
+// All kernels: one 64-lane wave per row, 16-byte loads, wave-shuffle reductions.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+// Sum of squares of a row in the lane-tree order (fp64), any dim (elements past dim = 0).
+__device__ inline double row_sumsq_lane_tree(const float *__restrict__ x, int dim) {
+    const int lane = lane_id();
+    const int nchunk = (dim + 3) >> 2;
+    const bool vec = ((dim & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    double acc = 0.0;
+    for (int c = lane; c < nchunk; c += WAVE) {
+        float v[4];
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4 *>(x + 4 * c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (4 * c + e < dim) ? x[4 * c + e] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fma((double)v[e], (double)v[e], acc);
+    }
+    return wave_butterfly_sum(acc);
+}
+
+// fp32 upper bound of sqrt(ss) (ss >= 0): round to nearest, then one ulp-ish up.
+__device__ inline float norm_upper(double ss) {
+    float f = (float)sqrt(ss);
+    return f * 1.0000002f + 1e-30f;
+}
+
+__global__ __launch_bounds__(256) void k_ingest(const float *__restrict__ src, int64_t n, int dim,
+                                                int dimp, float *__restrict__ g32,
+                                                uint16_t *__restrict__ g16,
+                                                float *__restrict__ gbias,
+                                                unsigned *__restrict__ gnorm_max_bits, int metric) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = lane_id();
+    const float *s = src + row * dim;
+    float *d32 = g32 + row * dimp;
+    uint16_t *d16 = g16 + row * dimp;
+    for (int e = lane; e < dimp; e += WAVE) {
+        const float v = e < dim ? s[e] : 0.0f;
+        d32[e] = v;
+        d16[e] = f32_to_bf16(v);
+    }
+    const double ss = row_sumsq_lane_tree(s, dim);
+    if (lane == 0) {
+        gbias[row] = metric == MIRX_METRIC_NEG_L2 ? (float)(-0.5 * ss) : 0.0f;
+        atomicMax(gnorm_max_bits, __float_as_uint(norm_upper(ss)));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prep_queries(const float *__restrict__ q, int64_t nq,
+                                                      int64_t nq_pad, int dim, int dimp,
+                                                      float *__restrict__ q32p,
+                                                      uint16_t *__restrict__ q16,
+                                                      float *__restrict__ qnorm) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nq_pad) return;
+    const int lane = lane_id();
+    float *d32 = q32p + row * dimp;
+    uint16_t *d16 = q16 + row * dimp;
+    if (row >= nq) {
+        for (int e = lane; e < dimp; e += WAVE) { d32[e] = 0.0f; d16[e] = 0; }
+        if (lane == 0) qnorm[row] = 0.0f;
+        return;
+    }
+    const float *s = q + row * dim;
+    for (int e = lane; e < dimp; e += WAVE) {
+        const float v = e < dim ? s[e] : 0.0f;
+        d32[e] = v;
+        d16[e] = f32_to_bf16(v);
+    }
+    const double ss = row_sumsq_lane_tree(s, dim);
+    if (lane == 0) qnorm[row] = norm_upper(ss);
+}
+
+__global__ __launch_bounds__(256) void k_l2_normalize(float *__restrict__ x, int64_t n, int dim) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float *r = x + row * dim;
+    const double ss = row_sumsq_lane_tree(r, dim);
+    double nrm = sqrt(ss);
+    if (nrm < 1e-12) nrm = 1e-12;
+    for (int e = lane_id(); e < dim; e += WAVE) r[e] = (float)((double)r[e] / nrm);
+}
+
+// One workgroup per image.  Pass 1: one wave per channel sums relu(x*scale+shift) over the
+// hw contiguous pixels (coalesced, shuffle reduce).  Pass 2: L2-normalise the c means.
+__global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
+                                              const float *__restrict__ scale,
+                                              const float *__restrict__ shift, int c, int hw,
+                                              int normalize, float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float mean_s[];   // [cpad] floats + 1 double
+    const int64_t b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const float *xb = x + b * (int64_t)c * hw;
+    const float inv = 1.0f / (float)hw;
+    for (int ch = wave; ch < c; ch += 4) {
+        const float sc = scale ? scale[ch] : 1.0f, sh = shift ? shift[ch] : 0.0f;
+        const float *p = xb + (int64_t)ch * hw;
+        float acc = 0.0f;
+        for (int i = lane; i < hw; i += WAVE) acc += fmaxf(fmaf(p[i], sc, sh), 0.0f);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) mean_s[ch] = acc * inv;
+    }
+    const int cpad = (c + 3) & ~3;
+    double *nrm_s = reinterpret_cast<double *>(mean_s + cpad);
+    for (int i = c + threadIdx.x; i < cpad; i += 256) mean_s[i] = 0.0f;
+    __syncthreads();
+    if (normalize) {
+        if (wave == 0) {
+            const double ss = row_sumsq_lane_tree(mean_s, c);
+            double nrm = sqrt(ss);
+            if (nrm < 1e-12) nrm = 1e-12;
+            if (lane == 0) *nrm_s = nrm;
+        }
+        __syncthreads();
+        const double nrm = *nrm_s;
+        for (int i = threadIdx.x; i < c; i += 256) y[b * c + i] = (float)((double)mean_s[i] / nrm);
+    } else {
+        for (int i = threadIdx.x; i < c; i += 256) y[b * c + i] = mean_s[i];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_ingest(const float *src, int64_t n, int dim, int dimp, float *g32,
+                         uint16_t *g16, float *gbias, unsigned *gnorm_max_bits, int metric,
+                         hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, src, n, dim, dimp,
+                       g32, g16, gbias, gnorm_max_bits, metric);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_queries(const float *q, int64_t nq, int64_t nq_pad, int dim, int dimp,
+                               float *q32p, uint16_t *q16, float *qnorm, hipStream_t st) {
+    if (nq_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_queries, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, q, nq,
+                       nq_pad, dim, dimp, q32p, q16, qnorm);
+    return hipGetLastError();
+}
+
+hipError_t launch_l2_normalize(float *x, int64_t n, int dim, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_l2_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, dim);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shift,
+                                     int64_t n, int c, int hw, int normalize, float *y,
+                                     hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const size_t lds = (size_t)((c + 3) & ~3) * sizeof(float) + 16;
+    hipLaunchKernelGGL(k_head, dim3((unsigned)n), dim3(256), lds, st, x, scale, shift, c, hw,
+                       normalize, y);
+    return hipGetLastError();
+}
+
+}  // namespace mirx

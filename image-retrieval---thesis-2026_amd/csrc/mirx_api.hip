@@ -1,0 +1,528 @@
+// mirx_api.hip -- the C ABI (include/mirx.h): index object, search orchestration.
+//
+// A search is a fixed sequence of launches on the caller's stream:
+//   prep queries -> [group-max GEMM on a strided row sample -> thresholds] -> filter GEMM
+//   -> finalize (sort candidates, completeness guard, fp64 re-rank, top-k)
+//   -> exact scan (fp64 score tiles + row top-k) for the queries the guard rejected.
+// The only host<->device synchronisation is one read of the rejected-query count.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <mutex>
+#include <vector>
+
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace mirx
+
+using namespace mirx;
+
+struct mirx_index {
+    int dim = 0, dimp = 0, metric = 0, device = 0;
+    int64_t size = 0, cap = 0;
+    float *g32 = nullptr;
+    uint16_t *g16 = nullptr;
+    int64_t *ids = nullptr;
+    float *gbias = nullptr;
+    unsigned *gnorm_max_bits = nullptr;   // device scalar
+    // options
+    int tiers = MIRX_TIER_AUTO;
+    int sample_rank = 8;
+    uint32_t force_tau_bits = 0x7fc00000u;
+    // workspace
+    DevBuf q32p, q16, qnorm, tau, cnt, cand, groupmax, fail_list, scores, stage, rankwork;
+    int *fail_count = nullptr;            // device
+    mirx_search_stats *stats_dev = nullptr;
+    int *fail_count_host = nullptr;       // pinned
+    mirx_search_stats stats_host{};
+};
+
+namespace {
+
+constexpr int64_t QUERY_BATCH = 8192;          // queries per internal pass
+constexpr int64_t TIER1_MIN_ROWS = 32768;      // below this the exact scan answers directly
+constexpr int TIER1_MAX_K = 64;
+constexpr size_t EXACT_WS_BYTES = (size_t)1 << 30;   // fp64 score tile workspace per pass
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int is_device_pointer(const void *p, bool *dev) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unregistered host memory reports an error: treat as host
+        *dev = false;
+        return MIRX_OK;
+    }
+    *dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+    return MIRX_OK;
+}
+
+int grow(mirx_index *ix, int64_t want_rows) {
+    if (want_rows <= ix->cap) return MIRX_OK;
+    int64_t ncap = std::max<int64_t>(ix->cap * 2, want_rows);
+    ncap = round_up(std::max<int64_t>(ncap, ROW_ALIGN), ROW_ALIGN);
+    float *n32 = nullptr;
+    uint16_t *n16 = nullptr;
+    int64_t *nid = nullptr;
+    float *nb = nullptr;
+    const size_t b32 = (size_t)ncap * ix->dimp * sizeof(float);
+    const size_t b16 = (size_t)ncap * ix->dimp * sizeof(uint16_t);
+    hipError_t e;
+    if ((e = hipMalloc(&n32, b32)) != hipSuccess || (e = hipMalloc(&n16, b16)) != hipSuccess ||
+        (e = hipMalloc(&nid, (size_t)ncap * sizeof(int64_t))) != hipSuccess ||
+        (e = hipMalloc(&nb, (size_t)ncap * sizeof(float))) != hipSuccess) {
+        if (n32) (void)hipFree(n32);
+        if (n16) (void)hipFree(n16);
+        if (nid) (void)hipFree(nid);
+        if (nb) (void)hipFree(nb);
+        return fail(MIRX_ENOMEM, std::string("index grow: ") + hipGetErrorString(e));
+    }
+    // rows past `size` must read as zeros (tiles run over the padded tail)
+    MIRX_HIP(hipMemset(n32, 0, b32));
+    MIRX_HIP(hipMemset(n16, 0, b16));
+    MIRX_HIP(hipMemset(nid, 0xFF, (size_t)ncap * sizeof(int64_t)));
+    MIRX_HIP(hipMemset(nb, 0, (size_t)ncap * sizeof(float)));
+    if (ix->size > 0) {
+        MIRX_HIP(hipMemcpy(n32, ix->g32, (size_t)ix->size * ix->dimp * sizeof(float), hipMemcpyDeviceToDevice));
+        MIRX_HIP(hipMemcpy(n16, ix->g16, (size_t)ix->size * ix->dimp * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+        MIRX_HIP(hipMemcpy(nid, ix->ids, (size_t)ix->size * sizeof(int64_t), hipMemcpyDeviceToDevice));
+        MIRX_HIP(hipMemcpy(nb, ix->gbias, (size_t)ix->size * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (ix->g32) (void)hipFree(ix->g32);
+    if (ix->g16) (void)hipFree(ix->g16);
+    if (ix->ids) (void)hipFree(ix->ids);
+    if (ix->gbias) (void)hipFree(ix->gbias);
+    ix->g32 = n32;
+    ix->g16 = n16;
+    ix->ids = nid;
+    ix->gbias = nb;
+    ix->cap = ncap;
+    return MIRX_OK;
+}
+
+// Exact scan for `nlist` queries given by a device list (or 0..nlist-1 when list == null).
+int exact_pass(mirx_index *ix, const float *q32p, const int32_t *list_dev, int64_t nlist, int k,
+               const int64_t *exclude, double *out_f64, int64_t *out_ids, float *out_val,
+               hipStream_t st) {
+    if (nlist <= 0) return MIRX_OK;
+    const int64_t ld = round_up(std::max<int64_t>(ix->size, 1), 64);
+    int64_t per = (int64_t)(EXACT_WS_BYTES / ((size_t)ld * sizeof(double)));
+    per = std::max<int64_t>(4, std::min<int64_t>(per, 4096)) / 4 * 4;
+    per = std::min<int64_t>(per, round_up(nlist, 4));
+    MIRX_HIP(ix->scores.ensure((size_t)per * ld * sizeof(double)));
+    for (int64_t b = 0; b < nlist; b += per) {
+        const int cnt = (int)std::min<int64_t>(per, nlist - b);
+        const int32_t *lst = list_dev ? list_dev + b : nullptr;
+        // without a list the query index is the position: shift the base pointers instead
+        const float *qb = list_dev ? q32p : q32p + b * ix->dimp;
+        const int64_t *exb = exclude ? (list_dev ? exclude : exclude + b) : nullptr;
+        double *of = list_dev ? out_f64 : out_f64 + b * k;
+        int64_t *oi = list_dev ? out_ids : out_ids + b * k;
+        float *ov = out_val ? (list_dev ? out_val : out_val + b * k) : nullptr;
+        MIRX_HIP(launch_scores_f64(qb, lst, cnt, ix->g32, ix->size, ix->dimp, ix->metric,
+                                   ix->scores.as<double>(), ld, st));
+        MIRX_HIP(launch_row_topk(ix->scores.as<double>(), ld, ix->size, ix->ids, lst, cnt, exb, k,
+                                 ix->metric, of, oi, ov, st));
+    }
+    return MIRX_OK;
+}
+
+int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude,
+                float *out_val, double *out_f64_user, int64_t *out_ids, hipStream_t st) {
+    MIRX_CHECK(ix && q && out_ids, "search: null argument");
+    MIRX_CHECK(k >= 1 && k <= MAX_K, "search: k must be in [1, 1024]");
+    MIRX_CHECK(nq >= 0, "search: nq < 0");
+    DeviceGuard dg(ix->device);
+    if (!dg.ok) return fail(MIRX_EHIP, "search: cannot select the index device");
+    MIRX_HIP(hipMemsetAsync(ix->stats_dev, 0, sizeof(mirx_search_stats), st));
+    ix->stats_host = mirx_search_stats{};
+    ix->stats_host.nq = nq;
+    if (nq == 0) return MIRX_OK;
+
+    const bool tier1 = ix->tiers == MIRX_TIER_AUTO && ix->size >= TIER1_MIN_ROWS &&
+                       k + (exclude ? 1 : 0) <= TIER1_MAX_K;
+    for (int64_t q0 = 0; q0 < nq; q0 += QUERY_BATCH) {
+        const int64_t nb = std::min<int64_t>(QUERY_BATCH, nq - q0);
+        const int bn = gemm_query_tile(nb);
+        const int64_t nb_pad = round_up(nb, bn);
+        const float *qb = q + q0 * ix->dim;
+        const int64_t *exb = exclude ? exclude + q0 : nullptr;
+        float *ovb = out_val ? out_val + q0 * k : nullptr;
+        int64_t *oib = out_ids + q0 * k;
+        // fp64 ranking scores are always produced (user buffer or workspace)
+        double *ofb;
+        if (out_f64_user) {
+            ofb = out_f64_user + q0 * k;
+        } else {
+            MIRX_HIP(ix->stage.ensure((size_t)nb * k * sizeof(double)));
+            ofb = ix->stage.as<double>();
+        }
+
+        MIRX_HIP(ix->q32p.ensure((size_t)nb_pad * ix->dimp * sizeof(float)));
+        MIRX_HIP(ix->q16.ensure((size_t)nb_pad * ix->dimp * sizeof(uint16_t)));
+        MIRX_HIP(ix->qnorm.ensure((size_t)nb_pad * sizeof(float)));
+        MIRX_HIP(launch_prep_queries(qb, nb, nb_pad, ix->dim, ix->dimp, ix->q32p.as<float>(),
+                                     ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
+        if (ix->size == 0) {
+            // empty gallery: every slot is (-1, -inf); the exact pass does exactly that
+        }
+        if (!tier1) {
+            int rc = exact_pass(ix, ix->q32p.as<float>(), nullptr, nb, k, exb, ofb, oib, ovb, st);
+            if (rc) return rc;
+            ix->stats_host.exact_answered += nb;
+            continue;
+        }
+
+        // ---- tier 1 ---------------------------------------------------------------------
+        MIRX_HIP(ix->tau.ensure((size_t)nb_pad * sizeof(float)));
+        MIRX_HIP(ix->cnt.ensure((size_t)nb_pad * sizeof(int)));
+        MIRX_HIP(ix->cand.ensure((size_t)nb_pad * CAND_CAP * sizeof(Cand)));
+        MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
+        GemmArgs ga{};
+        ga.g16 = ix->g16;
+        ga.q16 = ix->q16.as<uint16_t>();
+        ga.gbias = ix->metric == MIRX_METRIC_NEG_L2 ? ix->gbias : nullptr;
+        ga.nq_pad = nb_pad;
+        ga.dimp = ix->dimp;
+        ga.tau = ix->tau.as<float>();
+        ga.cnt = ix->cnt.as<int>();
+        ga.cand = ix->cand.as<Cand>();
+        if (ix->force_tau_bits != 0x7fc00000u) {
+            // test hook: one fixed threshold for every query
+            std::vector<float> t((size_t)nb_pad, INFINITY);
+            float v;
+            std::memcpy(&v, &ix->force_tau_bits, 4);
+            std::fill(t.begin(), t.begin() + nb, v);
+            MIRX_HIP(hipMemcpyAsync(ix->tau.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            MIRX_HIP(hipStreamSynchronize(st));
+        } else {
+            // sample = every `stride`-th row, about size/32 rows, a multiple of the 256-row tile
+            int64_t ms = round_up(std::max<int64_t>(ix->size / 32, 4096), ROW_ALIGN);
+            ms = std::min<int64_t>(ms, 65536);
+            const int64_t stride = std::max<int64_t>(ix->size / ms, 1);
+            const int gpt = gemm_groups_per_tile(bn);
+            const int ngroups = (int)(ms / ROW_ALIGN) * gpt;
+            MIRX_HIP(ix->groupmax.ensure((size_t)nb_pad * ngroups * sizeof(float)));
+            GemmArgs gs = ga;
+            gs.n_rows = ms;
+            gs.row_stride = stride;
+            gs.groupmax = ix->groupmax.as<float>();
+            gs.ngroups = ngroups;
+            MIRX_HIP(launch_gemm_groupmax(gs, bn, st));
+            MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, ix->sample_rank,
+                                       ix->tau.as<float>(), st));
+        }
+        MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
+        MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, sizeof(int), st));
+        ga.n_rows = ix->size;
+        ga.row_stride = 1;
+        MIRX_HIP(launch_gemm_filter(ga, bn, st));
+
+        FinalizeArgs fa{};
+        fa.q32p = ix->q32p.as<float>();
+        fa.qnorm = ix->qnorm.as<float>();
+        fa.g32 = ix->g32;
+        fa.ids = ix->ids;
+        fa.gnorm_max_bits = ix->gnorm_max_bits;
+        fa.tau = ix->tau.as<float>();
+        fa.cnt = ix->cnt.as<int>();
+        fa.cand = ix->cand.as<Cand>();
+        fa.exclude = exb;
+        fa.n_rows = ix->size;
+        fa.dimp = ix->dimp;
+        fa.k = k;
+        fa.metric = ix->metric;
+        fa.nq = (int)nb;
+        fa.out_f64 = ofb;
+        fa.out_ids = oib;
+        fa.out_val = ovb;
+        fa.fail_list = ix->fail_list.as<int32_t>();
+        fa.fail_count = ix->fail_count;
+        fa.stats = ix->stats_dev;
+        MIRX_HIP(launch_finalize(fa, st));
+        MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        MIRX_HIP(hipStreamSynchronize(st));
+        const int nfail = *ix->fail_count_host;
+        if (nfail > 0) {
+            int rc = exact_pass(ix, ix->q32p.as<float>(), ix->fail_list.as<int32_t>(), nfail, k, exb, ofb,
+                                oib, ovb, st);
+            if (rc) return rc;
+            ix->stats_host.exact_answered += nfail;
+        }
+    }
+    return MIRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mirx_last_error(void) { return g_err.c_str(); }
+int mirx_version(void) { return MIRX_VERSION; }
+
+int mirx_index_create(int dim, int metric, int device, mirx_index **out) {
+    MIRX_CHECK(out, "index_create: out is null");
+    *out = nullptr;
+    MIRX_CHECK(dim >= 1 && round_up(dim, DIM_ALIGN) <= MAX_DIMP, "index_create: dim out of range");
+    MIRX_CHECK(metric == MIRX_METRIC_IP || metric == MIRX_METRIC_NEG_L2, "index_create: unknown metric");
+    int ndev = 0;
+    MIRX_HIP(hipGetDeviceCount(&ndev));
+    MIRX_CHECK(device >= 0 && device < ndev, "index_create: no such device");
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail(MIRX_EHIP, "index_create: cannot select device");
+    mirx_index *ix = new (std::nothrow) mirx_index();
+    if (!ix) return fail(MIRX_ENOMEM, "index_create: host allocation failed");
+    ix->dim = dim;
+    ix->dimp = (int)round_up(dim, DIM_ALIGN);
+    ix->metric = metric;
+    ix->device = device;
+    hipError_t e;
+    if ((e = hipMalloc(&ix->gnorm_max_bits, sizeof(unsigned))) != hipSuccess ||
+        (e = hipMemset(ix->gnorm_max_bits, 0, sizeof(unsigned))) != hipSuccess ||
+        (e = hipMalloc(&ix->fail_count, sizeof(int))) != hipSuccess ||
+        (e = hipMalloc(&ix->stats_dev, sizeof(mirx_search_stats))) != hipSuccess ||
+        (e = hipMemset(ix->stats_dev, 0, sizeof(mirx_search_stats))) != hipSuccess ||
+        (e = hipHostMalloc(&ix->fail_count_host, sizeof(int))) != hipSuccess) {
+        mirx_index_destroy(ix);
+        return fail(MIRX_ENOMEM, std::string("index_create: ") + hipGetErrorString(e));
+    }
+    *out = ix;
+    return MIRX_OK;
+}
+
+void mirx_index_destroy(mirx_index *ix) {
+    if (!ix) return;
+    DeviceGuard dg(ix->device);
+    if (ix->g32) (void)hipFree(ix->g32);
+    if (ix->g16) (void)hipFree(ix->g16);
+    if (ix->ids) (void)hipFree(ix->ids);
+    if (ix->gbias) (void)hipFree(ix->gbias);
+    if (ix->gnorm_max_bits) (void)hipFree(ix->gnorm_max_bits);
+    if (ix->fail_count) (void)hipFree(ix->fail_count);
+    if (ix->stats_dev) (void)hipFree(ix->stats_dev);
+    if (ix->fail_count_host) (void)hipHostFree(ix->fail_count_host);
+    for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->groupmax,
+                      &ix->fail_list, &ix->scores, &ix->stage, &ix->rankwork})
+        b->release();
+    delete ix;
+}
+
+int mirx_index_reserve(mirx_index *ix, int64_t capacity_rows) {
+    MIRX_CHECK(ix && capacity_rows >= 0, "index_reserve: bad argument");
+    DeviceGuard dg(ix->device);
+    return grow(ix, capacity_rows);
+}
+
+int64_t mirx_index_size(const mirx_index *ix) { return ix ? ix->size : -1; }
+int mirx_index_dim(const mirx_index *ix) { return ix ? ix->dim : -1; }
+
+int mirx_index_set_option(mirx_index *ix, int option, int64_t value) {
+    MIRX_CHECK(ix, "set_option: null index");
+    switch (option) {
+        case MIRX_OPT_TIERS:
+            MIRX_CHECK(value == MIRX_TIER_AUTO || value == MIRX_TIER_EXACT_ONLY, "set_option: bad tier");
+            ix->tiers = (int)value;
+            return MIRX_OK;
+        case MIRX_OPT_SAMPLE_RANK:
+            MIRX_CHECK(value >= 1 && value <= 256, "set_option: sample rank out of range");
+            ix->sample_rank = (int)value;
+            return MIRX_OK;
+        case MIRX_OPT_FORCE_TAU:
+            ix->force_tau_bits = (uint32_t)value;
+            return MIRX_OK;
+        default:
+            return fail(MIRX_EINVAL, "set_option: unknown option");
+    }
+}
+
+int mirx_index_add(mirx_index *ix, const float *rows, int64_t n, const int64_t *ids_or_null) {
+    MIRX_CHECK(ix && n >= 0 && (rows || n == 0), "index_add: bad argument");
+    if (n == 0) return MIRX_OK;
+    MIRX_CHECK(ix->size + n <= 0x7FFFFF00ll, "index_add: more than 2^31 rows per index");
+    DeviceGuard dg(ix->device);
+    if (!dg.ok) return fail(MIRX_EHIP, "index_add: cannot select device");
+    int rc = grow(ix, ix->size + n);
+    if (rc) return rc;
+    bool rows_dev = false, ids_dev = false;
+    is_device_pointer(rows, &rows_dev);
+    if (ids_or_null) is_device_pointer(ids_or_null, &ids_dev);
+    const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)ix->dim * 4));
+    for (int64_t b = 0; b < n; b += chunk) {
+        const int64_t m = std::min(chunk, n - b);
+        const float *src = rows + b * ix->dim;
+        if (!rows_dev) {
+            MIRX_HIP(ix->stage.ensure((size_t)m * ix->dim * sizeof(float)));
+            MIRX_HIP(hipMemcpy(ix->stage.p, src, (size_t)m * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+            src = ix->stage.as<float>();
+        }
+        const int64_t at = ix->size + b;
+        MIRX_HIP(launch_ingest(src, m, ix->dim, ix->dimp, ix->g32 + at * ix->dimp, ix->g16 + at * ix->dimp,
+                               ix->gbias + at, ix->gnorm_max_bits, ix->metric, nullptr));
+        MIRX_HIP(hipStreamSynchronize(nullptr));
+    }
+    if (ids_or_null) {
+        MIRX_HIP(hipMemcpy(ix->ids + ix->size, ids_or_null, (size_t)n * sizeof(int64_t),
+                           ids_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        std::vector<int64_t> auto_ids((size_t)n);
+        for (int64_t i = 0; i < n; ++i) auto_ids[(size_t)i] = ix->size + i;
+        MIRX_HIP(hipMemcpy(ix->ids + ix->size, auto_ids.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    ix->size += n;
+    return MIRX_OK;
+}
+
+int mirx_index_get_rows(const mirx_index *ix, int64_t first, int64_t n, float *out_rows,
+                        int64_t *out_ids_or_null) {
+    MIRX_CHECK(ix && out_rows && first >= 0 && n >= 0 && first + n <= ix->size, "get_rows: bad range");
+    DeviceGuard dg(ix->device);
+    MIRX_HIP(hipMemcpy2D(out_rows, (size_t)ix->dim * sizeof(float), ix->g32 + first * ix->dimp,
+                         (size_t)ix->dimp * sizeof(float), (size_t)ix->dim * sizeof(float), (size_t)n,
+                         hipMemcpyDefault));
+    if (out_ids_or_null)
+        MIRX_HIP(hipMemcpy(out_ids_or_null, ix->ids + first, (size_t)n * sizeof(int64_t), hipMemcpyDefault));
+    return MIRX_OK;
+}
+
+int mirx_index_search(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude_ids_or_null,
+                      float *out_scores, int64_t *out_ids, void *stream) {
+    MIRX_CHECK(out_scores, "search: out_scores is null");
+    return search_impl(ix, q, nq, k, exclude_ids_or_null, out_scores, nullptr, out_ids,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
+                          const int64_t *exclude_ids_or_null, double *out_rank_scores, int64_t *out_ids,
+                          void *stream) {
+    MIRX_CHECK(out_rank_scores, "search_f64: out_rank_scores is null");
+    return search_impl(ix, q, nq, k, exclude_ids_or_null, nullptr, out_rank_scores, out_ids,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out) {
+    MIRX_CHECK(ix && out, "last_stats: null argument");
+    DeviceGuard dg(ix->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MIRX_HIP(hipStreamSynchronize(st));
+    mirx_search_stats d{};
+    MIRX_HIP(hipMemcpy(&d, ix->stats_dev, sizeof(d), hipMemcpyDeviceToHost));
+    *out = d;
+    out->nq = ix->stats_host.nq;
+    out->exact_answered = ix->stats_host.exact_answered;
+    return MIRX_OK;
+}
+
+int mirx_index_rank_all(mirx_index *ix, const float *q, int64_t nq, const int64_t *exclude_ids_or_null,
+                        int64_t *out_ids, float *out_scores_or_null, void *stream) {
+    MIRX_CHECK(ix && q && out_ids && nq >= 0, "rank_all: bad argument");
+    MIRX_CHECK(ix->size <= 65536, "rank_all: gallery larger than 65536 rows");
+    if (nq == 0 || ix->size == 0) return MIRX_OK;
+    DeviceGuard dg(ix->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = ix->size;
+    int64_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const int64_t ld = round_up(n, 64);
+    int64_t per = std::max<int64_t>(4, std::min<int64_t>(1024, (int64_t)((size_t)1 << 29) / (np2 * 16))) / 4 * 4;
+    per = std::min<int64_t>(per, round_up(nq, 4));
+    MIRX_HIP(ix->scores.ensure((size_t)per * ld * sizeof(double)));
+    MIRX_HIP(ix->rankwork.ensure((size_t)per * np2 * sizeof(Hit)));
+    MIRX_HIP(ix->q32p.ensure((size_t)per * ix->dimp * sizeof(float)));
+    MIRX_HIP(ix->q16.ensure((size_t)per * ix->dimp * sizeof(uint16_t)));
+    MIRX_HIP(ix->qnorm.ensure((size_t)per * sizeof(float)));
+    for (int64_t b = 0; b < nq; b += per) {
+        const int cnt = (int)std::min<int64_t>(per, nq - b);
+        MIRX_HIP(launch_prep_queries(q + b * ix->dim, cnt, cnt, ix->dim, ix->dimp, ix->q32p.as<float>(),
+                                     ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
+        MIRX_HIP(launch_scores_f64(ix->q32p.as<float>(), nullptr, cnt, ix->g32, n, ix->dimp, ix->metric,
+                                   ix->scores.as<double>(), ld, st));
+        MIRX_HIP(launch_rank_rows(ix->scores.as<double>(), ld, n, ix->ids,
+                                  exclude_ids_or_null ? exclude_ids_or_null + b : nullptr, cnt,
+                                  ix->rankwork.as<Hit>(), np2, ix->metric, out_ids + b * n,
+                                  out_scores_or_null ? out_scores_or_null + b * n : nullptr, st));
+    }
+    return MIRX_OK;
+}
+
+int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, int64_t nq, int k,
+                    int metric, double *out_rank_scores, float *out_scores, int64_t *out_ids, void *stream) {
+    MIRX_CHECK(in_scores && in_ids && out_ids && nshard >= 1 && nq >= 0 && k >= 1, "topk_merge: bad argument");
+    MIRX_CHECK((int64_t)nshard * k <= 8192, "topk_merge: nshard * k must be <= 8192");
+    MIRX_HIP(launch_topk_merge(in_scores, in_ids, nshard, nq, k, metric, out_rank_scores, out_scores,
+                               out_ids, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_l2_normalize(float *x, int64_t n, int dim, void *stream) {
+    MIRX_CHECK(x && n >= 0 && dim >= 1, "l2_normalize: bad argument");
+    MIRX_HIP(launch_l2_normalize(x, n, dim, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shift, int64_t n, int c,
+                            int hw, int normalize, float *y, void *stream) {
+    MIRX_CHECK(x && y && n >= 0 && c >= 1 && c <= 16384 && hw >= 1, "bn_relu_gap_l2norm: bad argument");
+    MIRX_HIP(launch_bn_relu_gap_l2norm(x, scale, shift, n, c, hw, normalize, y,
+                                       reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *scale, const float *shift,
+                                 int64_t n, int h, int wd, float *y, void *stream) {
+    MIRX_CHECK(x && w && scale && shift && y && n >= 0, "stem: null argument");
+    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem: H and W must be multiples of 4");
+    MIRX_HIP(launch_stem(x, w, scale, shift, n, h, wd, y, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// mirx_common.h -- shared host/device helpers for libmirx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/mirx.h"
+
+namespace mirx {
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define MIRX_HIP(expr)                                                                     \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return ::mirx::fail(MIRX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define MIRX_CHECK(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) return ::mirx::fail(MIRX_EINVAL, (msg));   \
+    } while (0)
+
+// ---- sizes ----------------------------------------------------------------------------
+constexpr int WAVE = 64;
+constexpr int DIM_ALIGN = 64;        // rows are stored padded to a multiple of 64 elements
+constexpr int ROW_ALIGN = 256;       // gallery capacity is a multiple of the GEMM M tile
+constexpr int CAND_CAP = 1024;       // per-query candidate capacity of the threshold filter
+constexpr int MAX_K = 1024;
+constexpr int MAX_DIMP = 4096;
+
+struct Cand {          // one row that passed the bf16 threshold filter
+    float s;           // approximate score (bf16 MFMA, fp32 accumulate [+ bias])
+    int32_t row;       // gallery row
+};
+
+struct Hit {           // one exactly scored row
+    double s;          // fp64 ranking score (lane-tree order)
+    int64_t id;
+};
+
+// `a` ranks before `b`: higher score first, then lower id.
+__host__ __device__ inline bool hit_before(double sa, int64_t ia, double sb, int64_t ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+#ifdef __HIPCC__
+// ---- device helpers -------------------------------------------------------------------
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+
+__device__ inline double wave_butterfly_sum(double v) {
+    // s[l] = s[l] + s[l ^ off], off = 32..1 : the order search_ref.c pins.
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// fp32 -> bf16, round to nearest even (finite inputs).
+__device__ inline uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Lane-tree fp64 score of two fp32 rows of `dimp` (multiple of 64) elements.
+// METRIC 0: sum q*g ; METRIC 1: -(sum (q-g)^2).  All lanes return the same value.
+template <int METRIC>
+__device__ inline double lane_tree_score(const float *__restrict__ q, const float *__restrict__ g,
+                                         int dimp) {
+    const int lane = lane_id();
+    const int nchunk = dimp >> 2;
+    double acc = 0.0;
+    for (int c = lane; c < nchunk; c += WAVE) {
+        const float4 a = *reinterpret_cast<const float4 *>(q + 4 * c);
+        const float4 b = *reinterpret_cast<const float4 *>(g + 4 * c);
+        if (METRIC == 0) {
+            acc = fma((double)a.x, (double)b.x, acc);
+            acc = fma((double)a.y, (double)b.y, acc);
+            acc = fma((double)a.z, (double)b.z, acc);
+            acc = fma((double)a.w, (double)b.w, acc);
+        } else {
+            double d;
+            d = (double)a.x - (double)b.x; acc = fma(d, d, acc);
+            d = (double)a.y - (double)b.y; acc = fma(d, d, acc);
+            d = (double)a.z - (double)b.z; acc = fma(d, d, acc);
+            d = (double)a.w - (double)b.w; acc = fma(d, d, acc);
+        }
+    }
+    acc = wave_butterfly_sum(acc);
+    return METRIC == 0 ? acc : -acc;
+}
+#endif  // __HIPCC__
+
+}  // namespace mirx

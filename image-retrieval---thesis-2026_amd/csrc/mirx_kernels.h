@@ -1,0 +1,89 @@
+// mirx_kernels.h -- launch wrappers implemented in the k_*.hip files (internal, not ABI).
+#pragma once
+#include "mirx_common.h"
+
+namespace mirx {
+
+// ---- k_prep.hip -------------------------------------------------------------------------
+// Rows [n, dim] fp32 (device) -> padded fp32 master, bf16 copy, per-row bias (metric 1:
+// -0.5*||g||^2, metric 0: 0) and an atomic running maximum of ||g|| (upper bound, fp32 bits).
+hipError_t launch_ingest(const float *src, int64_t n, int dim, int dimp, float *g32,
+                         uint16_t *g16, float *gbias, unsigned *gnorm_max_bits, int metric,
+                         hipStream_t st);
+// Queries [nq, dim] fp32 -> padded fp32 [nq_pad, dimp], bf16 [nq_pad, dimp], upper bound of
+// ||q|| per query; rows nq..nq_pad-1 are zero.
+hipError_t launch_prep_queries(const float *q, int64_t nq, int64_t nq_pad, int dim, int dimp,
+                               float *q32p, uint16_t *q16, float *qnorm, hipStream_t st);
+hipError_t launch_l2_normalize(float *x, int64_t n, int dim, hipStream_t st);
+hipError_t launch_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shift,
+                                     int64_t n, int c, int hw, int normalize, float *y,
+                                     hipStream_t st);
+hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
+                       int64_t n, int h, int wd, float *y, hipStream_t st);
+
+// ---- k_exact.hip ------------------------------------------------------------------------
+// out[i*ld + j] = fp64 ranking score of query qlist[i] (or i when qlist == null) vs row j.
+hipError_t launch_scores_f64(const float *q32p, const int32_t *qlist, int nq, const float *g32,
+                             int64_t n, int dimp, int metric, double *out, int64_t ld,
+                             hipStream_t st);
+// Per query row of `scores` [nq, ld]: top-k by (score desc, id asc), skipping exclude ids.
+// Writes out_f64 / out_ids / out_val at row qlist[i] (or i) of the [*, k] outputs.
+hipError_t launch_row_topk(const double *scores, int64_t ld, int64_t n, const int64_t *ids,
+                           const int32_t *qlist, int nq, const int64_t *exclude, int k,
+                           int metric, double *out_f64, int64_t *out_ids, float *out_val,
+                           hipStream_t st);
+// Full sort of every row: hits [nq, np2] (np2 = power of two >= n) built from scores, sorted.
+hipError_t launch_rank_rows(const double *scores, int64_t ld, int64_t n, const int64_t *ids,
+                            const int64_t *exclude, int nq, Hit *work, int64_t np2, int metric,
+                            int64_t *out_ids, float *out_val, hipStream_t st);
+hipError_t launch_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard,
+                             int64_t nq, int k, int metric, double *out_f64, float *out_val,
+                             int64_t *out_ids, hipStream_t st);
+
+// ---- k_gemm.hip -------------------------------------------------------------------------
+struct GemmArgs {
+    const uint16_t *g16;   // gallery bf16 [rows, dimp]
+    const uint16_t *q16;   // queries bf16 [nq_pad, dimp]
+    const float *gbias;    // per-row bias (metric 1) or null
+    int64_t n_rows;        // valid gallery rows (filter mode) / sampled rows (group-max mode)
+    int64_t row_stride;    // gallery row step between consecutive tile rows (1 = dense)
+    int64_t nq_pad;        // multiple of the query tile
+    int dimp;
+    // filter mode
+    const float *tau;      // [nq_pad]
+    int *cnt;              // [nq_pad]
+    Cand *cand;            // [nq_pad, CAND_CAP]
+    // group-max mode
+    float *groupmax;       // [nq_pad, ngroups]
+    int ngroups;
+};
+int gemm_query_tile(int64_t nq);                 // query-tile width chosen for nq (64/128/256)
+int gemm_groups_per_tile(int bn);                // group-max groups per 256-row gallery tile
+hipError_t launch_gemm_filter(const GemmArgs &a, int bn, hipStream_t st);
+hipError_t launch_gemm_groupmax(const GemmArgs &a, int bn, hipStream_t st);
+
+// ---- k_finalize.hip ---------------------------------------------------------------------
+struct FinalizeArgs {
+    const float *q32p;       // [nq, dimp]
+    const float *qnorm;      // [nq]
+    const float *g32;        // [rows, dimp]
+    const int64_t *ids;      // [rows]
+    const unsigned *gnorm_max_bits;
+    const float *tau;
+    const int *cnt;
+    const Cand *cand;
+    const int64_t *exclude;  // or null
+    int64_t n_rows;
+    int dimp, k, metric, nq;
+    double *out_f64;         // [nq, k]
+    int64_t *out_ids;        // [nq, k]
+    float *out_val;          // [nq, k]
+    int32_t *fail_list;      // [nq]
+    int *fail_count;         // [1]
+    mirx_search_stats *stats;  // device copy
+};
+hipError_t launch_select_tau(const float *groupmax, int ngroups, int64_t nq, int64_t nq_pad,
+                             int rank_j, float *tau, hipStream_t st);
+hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t st);
+
+}  // namespace mirx

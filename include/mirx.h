@@ -1,0 +1,171 @@
+/*
+ * mirx.h -- C ABI of libmirx.so: MI355X-native exhaustive retrieval + embedding-head kernels.
+ *
+ * This is the drop-in boundary underneath the reference's Python protocol.  The reference
+ * (100 % Python, /root/reference) has no FFI of its own; each entry point below names the
+ * reference call it stands in for, and INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference adds at that call site.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a raw address, no torch/HIP C++ types;
+ *   - return 0 on success, a negative MIRX_E* code on failure; mirx_last_error() gives the
+ *     text for the calling thread; nothing throws across the ABI;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work of a
+ *     call is enqueued on it and the call returns without waiting unless stated;
+ *   - "device pointer" = memory of the index's device (hipMalloc / torch.cuda tensor
+ *     data_ptr()); "host pointer" = ordinary host memory.  mirx_index_add accepts either
+ *     (it asks the runtime); search inputs/outputs must be device pointers;
+ *   - the caller owns every buffer it passes; the index owns its device copies;
+ *   - an index is not re-entrant: add / search / destroy on one index must not overlap.
+ *
+ * Semantics of a search (pinned by oracle/search_ref.c):
+ *   score   = fp64 accumulation of the fp32 inputs in the fixed "lane tree" order
+ *   ranking = higher score first; equal scores -> lower id first
+ *   metric MIRX_METRIC_IP      score = <q, g>               (cosine on unit rows)
+ *   metric MIRX_METRIC_NEG_L2  ranks by -||q-g||^2, reports -||q-g||_2
+ * The bf16 MFMA pass only proposes candidates; every returned hit is re-scored in fp64 and
+ * a completeness guard proves that no better row was left out (otherwise the query falls
+ * through to the exact scan), so results never depend on which tier answered.
+ */
+#ifndef MIRX_H
+#define MIRX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRX_VERSION 100
+
+#define MIRX_OK 0
+#define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
+#define MIRX_ENOMEM (-2)   /* device or host allocation failed */
+#define MIRX_EHIP (-3)     /* a HIP runtime call failed; text in mirx_last_error() */
+#define MIRX_ESTATE (-4)   /* call not valid in the index's current state */
+
+#define MIRX_METRIC_IP 0
+#define MIRX_METRIC_NEG_L2 1
+
+/* search-tier selection (mirx_index_set_option MIRX_OPT_TIERS) */
+#define MIRX_TIER_AUTO 0        /* bf16 MFMA candidates + guard, exact scan for the rest   */
+#define MIRX_TIER_EXACT_ONLY 3  /* fp64 exact scan for every query (small galleries, tests) */
+
+#define MIRX_OPT_TIERS 1
+#define MIRX_OPT_SAMPLE_RANK 2   /* j: threshold = j-th largest sampled group maximum (default 8)  */
+#define MIRX_OPT_FORCE_TAU 3     /* test hook: float bits of a fixed threshold; 0x7fc00000 = off  */
+
+typedef struct mirx_index mirx_index;
+
+/* Counters of the most recent search on an index (host-visible after the stream is idle). */
+typedef struct mirx_search_stats {
+    int64_t nq;               /* queries in the call                                        */
+    int64_t tier1_answered;   /* answered by the bf16 MFMA pass + fp64 re-rank              */
+    int64_t exact_answered;   /* fell through to (or were routed to) the fp64 exact scan    */
+    int64_t candidates;       /* rows that passed the threshold, summed over queries        */
+    int64_t reranked;         /* rows re-scored in fp64 by tier 1, summed over queries      */
+    int64_t overflowed;       /* queries whose candidate list overflowed its capacity       */
+    int64_t incomplete;       /* queries whose completeness guard failed                    */
+} mirx_search_stats;
+
+const char *mirx_last_error(void);
+int mirx_version(void);
+
+/*
+ * Index lifetime.  Replaces: Collection(name, schema) + create_index + load
+ * (milvus/milvus_setup.py:139-222) -- an in-process, device-resident flat index.
+ * `dim` is the embedding width (any value >= 1; rows are stored padded to 64).
+ */
+int mirx_index_create(int dim, int metric, int device, mirx_index **out);
+void mirx_index_destroy(mirx_index *ix);
+
+/*
+ * Append n rows.  Replaces collection.insert([paths, labels, embeddings.tolist()])
+ * (ingest_embeddings.py:399-411) for the embedding column; path/label metadata stay with the
+ * Python Retriever.  rows: row-major [n, dim] fp32, host or device.  ids: n int64 (host or
+ * device) or NULL for auto ids (previous size + i, Milvus auto_id analogue,
+ * milvus_setup.py:170).  Synchronous: returns when the rows are resident.
+ */
+int mirx_index_add(mirx_index *ix, const float *rows, int64_t n, const int64_t *ids_or_null);
+int mirx_index_reserve(mirx_index *ix, int64_t capacity_rows);
+int64_t mirx_index_size(const mirx_index *ix);
+int mirx_index_dim(const mirx_index *ix);
+int mirx_index_set_option(mirx_index *ix, int option, int64_t value);
+
+/* Copy rows [first, first+n) of the fp32 master back out (device or host destination). */
+int mirx_index_get_rows(const mirx_index *ix, int64_t first, int64_t n, float *out_rows,
+                        int64_t *out_ids_or_null);
+
+/*
+ * Exhaustive top-k.  Replaces collection.search(data=[q], anns_field="embedding", limit=k)
+ * (milvus/milvus_retrieval.py:80-86, nih_zilliz_utils.py:263-270) and the brute force
+ * `-torch.cdist` / `e @ e.t()` + fill_diagonal_(-inf) + topk of test.py:1080-1085,44.
+ *   q            device, [nq, dim] fp32 row-major
+ *   exclude_ids  device, nq int64 or NULL: gallery rows with this id are skipped for query i
+ *                (the -inf diagonal of test.py:1081); use -1 for "nothing"
+ *   out_scores   device, [nq, k] fp32: reported value (metric 0: dot; metric 1: -L2)
+ *   out_ids      device, [nq, k] int64; slots past the number of eligible rows: id -1, -inf
+ *   1 <= k <= 1024
+ */
+int mirx_index_search(mirx_index *ix, const float *q, int64_t nq, int k,
+                      const int64_t *exclude_ids_or_null, float *out_scores, int64_t *out_ids,
+                      void *stream);
+
+/* fp64 ranking scores of the same hits ([nq, k] device doubles) for bit-exact parity tests. */
+int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
+                          const int64_t *exclude_ids_or_null, double *out_rank_scores,
+                          int64_t *out_ids, void *stream);
+
+/* Waits for `stream`, then copies the counters of the last search. */
+int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out);
+
+/*
+ * Full ranking of every gallery row for each query (row = query): replaces
+ * torch.argsort(dists, dim=0, descending=True) (test.py:1090,179) and the
+ * top_k = num_entities search of query_nih_zilliz.py:53-63.  out_ids: device [nq, size]
+ * int64 (excluded row last); out_scores_or_null: device [nq, size] fp32 reported values.
+ * Gallery size limited to 65536 rows per call in this version.
+ */
+int mirx_index_rank_all(mirx_index *ix, const float *q, int64_t nq,
+                        const int64_t *exclude_ids_or_null, int64_t *out_ids,
+                        float *out_scores_or_null, void *stream);
+
+/*
+ * Merge per-shard top-k lists (multi-GPU: after the all-gather of SURVEY 8e).
+ * in_scores/in_ids: device [nshard, nq, k] fp64 ranking scores / int64 ids; out: [nq, k].
+ * Same order rule as search (score desc, id asc); id -1 entries sort last.
+ */
+int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, int64_t nq,
+                    int k, int metric, double *out_rank_scores, float *out_scores,
+                    int64_t *out_ids, void *stream);
+
+/*
+ * x <- x / max(||x||_2, 1e-12) row-wise, in place.  Replaces F.normalize(x, dim=1)
+ * (model.py:83,116,493,634; milvus_retrieval.py:63).  x: device [n, dim] fp32.
+ */
+int mirx_l2_normalize(float *x, int64_t n, int dim, void *stream);
+
+/*
+ * Embedding head: y[b, c] = mean_{hw} relu(x[b, c, h, w] * scale[c] + shift[c]), then the
+ * optional L2 normalisation of each row.  Replaces norm5 -> relu -> AdaptiveAvgPool2d(1)
+ * -> flatten -> F.normalize of model.py:59-60,73-74,83 in one pass over the feature map.
+ * x: device NCHW fp32 [n, c, hw]; scale/shift: device [c] (folded eval BatchNorm) or NULL
+ * for identity; y: device [n, c] fp32.
+ */
+int mirx_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shift, int64_t n,
+                            int c, int hw, int normalize, float *y, void *stream);
+
+/*
+ * DenseNet stem: conv 7x7 stride 2 pad 3 (3 -> 64 channels) + folded BatchNorm + ReLU +
+ * max-pool 3x3 stride 2 pad 1, NCHW fp32 in, NCHW fp32 out [n, 64, H/4, W/4].
+ * Replaces features.conv0/norm0/relu0/pool0 of torchvision densenet121 (model.py:53).
+ * w: device [64, 3, 7, 7]; scale/shift: device [64].  H, W multiples of 4.
+ */
+int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *scale,
+                                 const float *shift, int64_t n, int h, int wd, float *y,
+                                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRX_H */
