@@ -179,9 +179,10 @@ int exact_pass(mirx_index *ix, const float *q32p, const int32_t *list_dev, int64
 
 int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude,
                 float *out_val, double *out_f64_user, int64_t *out_ids, hipStream_t st) {
-    MIRX_CHECK(ix && q && out_ids, "search: null argument");
+    MIRX_CHECK(ix, "search: null index");
     MIRX_CHECK(k >= 1 && k <= MAX_K, "search: k must be in [1, 1024]");
     MIRX_CHECK(nq >= 0, "search: nq < 0");
+    MIRX_CHECK(nq == 0 || (q && out_ids && (out_val || out_f64_user)), "search: null buffer");
     DeviceGuard dg(ix->device);
     if (!dg.ok) return fail(MIRX_EHIP, "search: cannot select the index device");
     MIRX_HIP(hipMemsetAsync(ix->stats_dev, 0, sizeof(mirx_search_stats), st));
@@ -436,7 +437,6 @@ int mirx_index_get_rows(const mirx_index *ix, int64_t first, int64_t n, float *o
 
 int mirx_index_search(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude_ids_or_null,
                       float *out_scores, int64_t *out_ids, void *stream) {
-    MIRX_CHECK(out_scores, "search: out_scores is null");
     return search_impl(ix, q, nq, k, exclude_ids_or_null, out_scores, nullptr, out_ids,
                        reinterpret_cast<hipStream_t>(stream));
 }
@@ -444,7 +444,6 @@ int mirx_index_search(mirx_index *ix, const float *q, int64_t nq, int k, const i
 int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
                           const int64_t *exclude_ids_or_null, double *out_rank_scores, int64_t *out_ids,
                           void *stream) {
-    MIRX_CHECK(out_rank_scores, "search_f64: out_rank_scores is null");
     return search_impl(ix, q, nq, k, exclude_ids_or_null, nullptr, out_rank_scores, out_ids,
                        reinterpret_cast<hipStream_t>(stream));
 }
