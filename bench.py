@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the hot path: DenseNet-121 embed (224x224) + exact top-10 over a
+resident 1M x 1024 gallery (BASELINE.json metric), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" on every rank: embed `--queries` synthetic images (micro-batches of
+`--embed-batch`, already resident in HBM), all-gather the embeddings (N > 1), exact top-10 of
+ALL N*queries embeddings against the local gallery shard (1M/N rows; bf16 MFMA candidates +
+fp64 re-rank in libmirx), one all-gather of the per-shard candidates, merge.  Per-GPU work is
+constant in N (weak scaling): value = N * queries * steps / max-over-ranks time.
+
+Extra objects on the JSON line (tier contract):
+  roofline      the distance GEMM (k_gemm filter pass): algorithmic 2*Q*N_shard*D FLOP per
+                launch / its HIP-event duration measured inside the timed steps, vs the dense
+                bf16 MFMA peak 2516.6 TFLOP/s (256 CU x 2.4 GHz x 4096 FLOP/clk/CU).
+  cpu_baseline  the reference's CPU path re-created with the same torch calls
+                (`-torch.cdist` + topk, test.py:1080,44) and the oracle DenseNet restatement,
+                timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2516.6
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (all GPUs)")
+    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--queries", type=int, default=4096, help="queries (images) per GPU per step")
+    ap.add_argument("--embed-batch", type=int, default=256)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--search-only", action="store_true", help="skip the embed stage (dev aid; not the metric)")
+    return ap.parse_args()
+
+
+def synthetic_images(batch, size, seed, device):
+    """torch.rand in [0,1) then ImageNet normalisation (test.py:1309-1310), on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.rand((batch, 3, size, size), generator=g, device=device)
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def gallery_chunk(chunk_idx, rows, dim, device):
+    g = torch.Generator(device=device).manual_seed(1234 + chunk_idx)
+    return torch.nn.functional.normalize(torch.randn((rows, dim), generator=g, device=device), dim=1)
+
+
+def build_shard(index, lo, hi, dim, device, chunk=1 << 16):
+    """Rows [lo, hi) of the seeded synthetic gallery; chunking is global so shards tile it."""
+    index.reserve(hi - lo)
+    c0, c1 = lo // chunk, (hi - 1) // chunk if hi > lo else -1
+    for c in range(c0, c1 + 1):
+        rows = gallery_chunk(c, chunk, dim, device)
+        a, b = max(lo, c * chunk), min(hi, (c + 1) * chunk)
+        index.add(rows[a - c * chunk: b - c * chunk], torch.arange(a, b, device=device))
+
+
+def cpu_baseline(index, model, args, dev):
+    """Reference CPU path on a bounded sample: embed 16 images + cdist/topk of 32 queries."""
+    from oracle import densenet as OD
+    nthreads = torch.get_num_threads()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    imgs = synthetic_images(16, args.image_size, 777, dev).cpu()
+    with torch.no_grad():
+        OD.embed(imgs[:2], sd)
+        t0 = time.perf_counter()
+        emb = OD.embed(imgs, sd)
+        t_embed = (time.perf_counter() - t0) / imgs.shape[0]
+    g_host = torch.empty((len(index), args.dim), dtype=torch.float32)
+    step = 1 << 17
+    for s in range(0, len(index), step):
+        rows, _ = index.rows(s, min(step, len(index) - s))
+        g_host[s:s + rows.shape[0]] = rows.cpu()
+    q = torch.nn.functional.normalize(torch.randn(32, args.dim, generator=torch.Generator().manual_seed(4321)), dim=1)
+    q[: emb.shape[0]] = emb
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        d = -torch.cdist(q, g_host)
+        d.topk(args.k, 1, True, True)
+        t_search = (time.perf_counter() - t0) / q.shape[0]
+    return {"value": 1.0 / (t_embed + t_search), "unit": "queries/s", "cores": nthreads, "kind": "port",
+            "sample": f"16 images embedded (oracle DenseNet-121 fp32, {1.0 / t_embed:.1f} img/s) + 32 queries "
+                      f"-torch.cdist+topk({args.k}) over {len(index)}x{args.dim} fp32 ({1.0 / t_search:.1f} q/s); "
+                      f"torch CPU threads={nthreads}, os.cpu_count={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if args.gpus > 1:
+            sys.exit(2)
+    import torch.distributed as dist
+    from mirx import _lib
+    from mirx.dist import ShardedSearcher, shard_bounds
+    from mirx.index import FlatIndex
+    from mirx.model import DenseNet121
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- resident state ------------------------------------------------------------------
+    torch.manual_seed(0)
+    model = DenseNet121().eval().to(dev)
+    index = FlatIndex(args.dim, "COSINE", local_rank)
+    lo, hi = shard_bounds(args.gallery, world, rank)
+    build_shard(index, lo, hi, args.dim, dev)
+    index.set_option(_lib.OPT_PROFILE, 1)
+    nmb = max(1, args.queries // args.embed_batch)
+    q_local = nmb * args.embed_batch
+    pool = [synthetic_images(args.embed_batch, args.image_size, 1234 + 97 * rank + i, dev) for i in range(min(4, nmb))]
+    fixed_q = torch.nn.functional.normalize(
+        torch.randn((q_local, args.dim), generator=torch.Generator(device=dev).manual_seed(4321 + rank), device=dev), dim=1)
+    searcher = ShardedSearcher(lambda qa, kk: index.search(qa, kk, return_f64=True), "COSINE")
+    emb = torch.empty((q_local, args.dim), dtype=torch.float32, device=dev)
+    gemm_ms, stage_ms = [], {}
+
+    def step(record):
+        with torch.no_grad():
+            if args.search_only:
+                emb.copy_(fixed_q)
+            else:
+                for i in range(nmb):
+                    emb[i * args.embed_batch:(i + 1) * args.embed_batch] = model(pool[i % len(pool)])
+            out = searcher.search(emb, args.k)
+        if record:
+            t = index.last_timings()          # waits for this search's events only
+            gemm_ms.append(t["gemm"])
+            for kname, v in t.items():
+                stage_ms[kname] = stage_ms.get(kname, 0.0) + v
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_q = world * q_local * args.steps
+    stats = index.last_stats()
+    if rank == 0:
+        dimp = (args.dim + 63) // 64 * 64
+        flop = 2.0 * (world * q_local) * (hi - lo) * dimp
+        avg_gemm_ms = sum(gemm_ms) / max(1, len(gemm_ms))
+        achieved = flop / (avg_gemm_ms * 1e-3) / 1e12 if avg_gemm_ms > 0 else 0.0
+        line = {
+            "metric": "queries/sec (embed+top-10) over 1M x 1024 gallery" if not args.search_only else "queries/sec (search only)",
+            "value": total_q / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 embed; bf16 MFMA candidates + f64 re-rank",
+            "data": "synthetic (rand 224x224 ImageNet-normalised images, seed-0 random-init DenseNet-121, "
+                    "unit-norm randn gallery seed 1234)",
+            "config": {"workload": f"DenseNet-121 embed {args.image_size}x{args.image_size} + exact top-{args.k} over "
+                                   f"{args.gallery}x{args.dim} fp32 gallery (cosine), {q_local} queries/GPU/step",
+                       "gallery_rows": args.gallery, "dim": args.dim, "queries_per_gpu_per_step": q_local,
+                       "embed_batch": args.embed_batch, "k": args.k,
+                       "sharding": f"gallery rows / {world} GPUs + 2 all-gathers" if world > 1 else "single GPU",
+                       "search_stats_last_step": stats,
+                       "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
+            "roofline": {"bound": "mfma", "kernel": "mirx::k_gemm<256,0,false> (bf16 MFMA distance GEMM + threshold filter)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop, "avg_launch_ms": avg_gemm_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(index, model, args, dev)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

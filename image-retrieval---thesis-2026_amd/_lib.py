@@ -16,6 +16,8 @@ TIER_EXACT_ONLY = 3
 OPT_TIERS = 1
 OPT_SAMPLE_RANK = 2
 OPT_FORCE_TAU = 3
+OPT_PROFILE = 4
+STAGES = ("prep", "sample", "gemm", "finalize", "exact")
 FORCE_TAU_OFF = 0x7FC00000
 
 
@@ -48,6 +50,7 @@ SYMBOLS = {
     "mirx_index_search": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mirx_index_search_f64": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mirx_index_last_stats": (_int, [_vp, _vp, ctypes.POINTER(SearchStats)]),
+    "mirx_index_last_timings": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "mirx_index_rank_all": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mirx_topk_merge": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),

@@ -68,6 +68,11 @@ struct mirx_index {
     int tiers = MIRX_TIER_AUTO;
     int sample_rank = 8;
     uint32_t force_tau_bits = 0x7fc00000u;
+    int profile = 0;
+    std::vector<hipEvent_t> ev_pool;      // lazily created, reused
+    struct Span { int stage; hipEvent_t a, b; };
+    std::vector<Span> spans;              // of the last search
+    size_t ev_used = 0;
     // workspace
     DevBuf q32p, q16, qnorm, tau, cnt, cand, groupmax, fail_list, scores, stage, rankwork;
     int *fail_count = nullptr;            // device
@@ -150,6 +155,33 @@ int grow(mirx_index *ix, int64_t want_rows) {
     return MIRX_OK;
 }
 
+struct StageTimer {
+    mirx_index *ix;
+    hipStream_t st;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(mirx_index *ix_, hipStream_t st_, int stage_) : ix(ix_), st(st_), stage(stage_) {
+        if (!ix->profile) return;
+        a = next();
+        b = next();
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    hipEvent_t next() {
+        if (ix->ev_used == ix->ev_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ix->ev_pool.push_back(e);
+        }
+        return ix->ev_pool[ix->ev_used++];
+    }
+    ~StageTimer() {
+        if (a && b) {
+            (void)hipEventRecord(b, st);
+            ix->spans.push_back({stage, a, b});
+        }
+    }
+};
+
 // Exact scan for `nlist` queries given by a device list (or 0..nlist-1 when list == null).
 int exact_pass(mirx_index *ix, const float *q32p, const int32_t *list_dev, int64_t nlist, int k,
                const int64_t *exclude, double *out_f64, int64_t *out_ids, float *out_val,
@@ -188,6 +220,8 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
     MIRX_HIP(hipMemsetAsync(ix->stats_dev, 0, sizeof(mirx_search_stats), st));
     ix->stats_host = mirx_search_stats{};
     ix->stats_host.nq = nq;
+    ix->spans.clear();
+    ix->ev_used = 0;
     if (nq == 0) return MIRX_OK;
 
     const bool tier1 = ix->tiers == MIRX_TIER_AUTO && ix->size >= TIER1_MIN_ROWS &&
@@ -212,12 +246,14 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         MIRX_HIP(ix->q32p.ensure((size_t)nb_pad * ix->dimp * sizeof(float)));
         MIRX_HIP(ix->q16.ensure((size_t)nb_pad * ix->dimp * sizeof(uint16_t)));
         MIRX_HIP(ix->qnorm.ensure((size_t)nb_pad * sizeof(float)));
-        MIRX_HIP(launch_prep_queries(qb, nb, nb_pad, ix->dim, ix->dimp, ix->q32p.as<float>(),
-                                     ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
-        if (ix->size == 0) {
-            // empty gallery: every slot is (-1, -inf); the exact pass does exactly that
+        {
+            StageTimer t(ix, st, MIRX_STAGE_PREP);
+            MIRX_HIP(launch_prep_queries(qb, nb, nb_pad, ix->dim, ix->dimp, ix->q32p.as<float>(),
+                                         ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
         }
         if (!tier1) {
+            // (an empty gallery lands here too: every slot becomes (-1, -inf))
+            StageTimer t(ix, st, MIRX_STAGE_EXACT);
             int rc = exact_pass(ix, ix->q32p.as<float>(), nullptr, nb, k, exb, ofb, oib, ovb, st);
             if (rc) return rc;
             ix->stats_host.exact_answered += nb;
@@ -259,6 +295,7 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
             gs.row_stride = stride;
             gs.groupmax = ix->groupmax.as<float>();
             gs.ngroups = ngroups;
+            StageTimer t(ix, st, MIRX_STAGE_SAMPLE);
             MIRX_HIP(launch_gemm_groupmax(gs, bn, st));
             MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, ix->sample_rank,
                                        ix->tau.as<float>(), st));
@@ -267,7 +304,10 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, sizeof(int), st));
         ga.n_rows = ix->size;
         ga.row_stride = 1;
-        MIRX_HIP(launch_gemm_filter(ga, bn, st));
+        {
+            StageTimer t(ix, st, MIRX_STAGE_GEMM);
+            MIRX_HIP(launch_gemm_filter(ga, bn, st));
+        }
 
         FinalizeArgs fa{};
         fa.q32p = ix->q32p.as<float>();
@@ -290,11 +330,15 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         fa.fail_list = ix->fail_list.as<int32_t>();
         fa.fail_count = ix->fail_count;
         fa.stats = ix->stats_dev;
-        MIRX_HIP(launch_finalize(fa, st));
+        {
+            StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
+            MIRX_HIP(launch_finalize(fa, st));
+        }
         MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
         MIRX_HIP(hipStreamSynchronize(st));
         const int nfail = *ix->fail_count_host;
         if (nfail > 0) {
+            StageTimer t(ix, st, MIRX_STAGE_EXACT);
             int rc = exact_pass(ix, ix->q32p.as<float>(), ix->fail_list.as<int32_t>(), nfail, k, exb, ofb,
                                 oib, ovb, st);
             if (rc) return rc;
@@ -352,6 +396,7 @@ void mirx_index_destroy(mirx_index *ix) {
     if (ix->fail_count) (void)hipFree(ix->fail_count);
     if (ix->stats_dev) (void)hipFree(ix->stats_dev);
     if (ix->fail_count_host) (void)hipHostFree(ix->fail_count_host);
+    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->groupmax,
                       &ix->fail_list, &ix->scores, &ix->stage, &ix->rankwork})
         b->release();
@@ -380,6 +425,9 @@ int mirx_index_set_option(mirx_index *ix, int option, int64_t value) {
             return MIRX_OK;
         case MIRX_OPT_FORCE_TAU:
             ix->force_tau_bits = (uint32_t)value;
+            return MIRX_OK;
+        case MIRX_OPT_PROFILE:
+            ix->profile = value ? 1 : 0;
             return MIRX_OK;
         default:
             return fail(MIRX_EINVAL, "set_option: unknown option");
@@ -458,6 +506,19 @@ int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out) 
     *out = d;
     out->nq = ix->stats_host.nq;
     out->exact_answered = ix->stats_host.exact_answered;
+    return MIRX_OK;
+}
+
+int mirx_index_last_timings(mirx_index *ix, float *out_ms) {
+    MIRX_CHECK(ix && out_ms, "last_timings: null argument");
+    DeviceGuard dg(ix->device);
+    for (int i = 0; i < MIRX_NUM_STAGES; ++i) out_ms[i] = 0.0f;
+    for (const auto &sp : ix->spans) {
+        MIRX_HIP(hipEventSynchronize(sp.b));
+        float ms = 0.0f;
+        MIRX_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        out_ms[sp.stage] += ms;
+    }
     return MIRX_OK;
 }
 

@@ -150,6 +150,12 @@ class FlatIndex:
                        "mirx_index_last_stats")
         return s.as_dict()
 
+    def last_timings(self):
+        """Stage -> milliseconds of the last search (needs set_option(OPT_PROFILE, 1))."""
+        arr = (ctypes.c_float * len(_lib.STAGES))()
+        _lib.check(self._lib.mirx_index_last_timings(self._h, arr), "mirx_index_last_timings")
+        return dict(zip(_lib.STAGES, [float(v) for v in arr]))
+
     def rows(self, first=0, n=None):
         n = len(self) - first if n is None else n
         out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)

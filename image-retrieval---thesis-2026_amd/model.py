@@ -1,0 +1,212 @@
+"""Embedding models with the reference's forward() contract (model.py of the reference).
+
+Contract kept (reference model.py:50-84): ``DenseNet121(pretrained, embedding_dim, num_labels)``,
+``forward(x: float[B,3,H,W]) -> float[B,D]`` with unit-norm rows (eps 1e-12), a dict with
+``"embedding"``/``"logits"`` when ``num_labels`` is set, attributes ``densenet121`` (Sequential
+whose child ``0`` is the feature stack and whose child ``avgpool`` is the pooling), ``fc``,
+``classification_head``; state-dict keys ``densenet121.0.conv0.weight``,
+``densenet121.0.denseblock1.denselayer1.norm1.weight``, ..., ``densenet121.0.norm5.*``,
+``fc.*`` load unchanged.
+
+The backbone is restated here from the published DenseNet-121 definition (Huang et al.;
+torchvision is NOT a dependency and is absent offline): conv0 7x7/2 (3->64), BN, ReLU,
+max-pool 3x3/2, dense blocks of (6, 12, 24, 16) layers [BN-ReLU-conv1x1(->128)-BN-ReLU-
+conv3x3(->32)], transitions [BN-ReLU-conv1x1(halve)-avgpool 2x2], norm5.  6 953 856
+feature parameters, final map [B,1024,H/32,W/32].
+
+MI355X path (CUDA tensors, eval mode):
+  * stem conv0+norm0+relu0+pool0 -> one HIP kernel (libmirx ``mirx_stem_conv7_bn_relu_pool``)
+  * dense blocks run under PyTorch-ROCm; each block owns ONE preallocated feature buffer and
+    every layer writes its 32 new channels into it (no O(L^2) torch.cat re-copies)
+  * norm5+relu+global-average-pool+flatten+F.normalize -> one HIP kernel
+    (``mirx_bn_relu_gap_l2norm``), or GAP only when an ``fc`` follows.
+``pretrained=True`` would need a download in the reference (model.py:53); here it raises
+unless a local state dict is given via ``weights=``.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+BLOCK_CONFIG = (6, 12, 24, 16)
+GROWTH = 32
+BN_SIZE = 4
+INIT_FEATURES = 64
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, BN_SIZE * GROWTH, kernel_size=1, stride=1, bias=False)
+        self.norm2 = nn.BatchNorm2d(BN_SIZE * GROWTH)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(BN_SIZE * GROWTH, GROWTH, kernel_size=3, stride=1, padding=1, bias=False)
+
+    def forward(self, x):
+        y = self.conv1(self.relu1(self.norm1(x)))
+        return self.conv2(self.relu2(self.norm2(y)))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, nlayers, cin):
+        super().__init__()
+        self.cin = cin
+        for i in range(nlayers):
+            self.add_module(f"denselayer{i + 1}", _DenseLayer(cin + i * GROWTH))
+
+    @property
+    def cout(self):
+        return self.cin + len(self) * GROWTH
+
+    def forward(self, x):
+        # one buffer for the whole block: layer i reads channels [0, cin + 32 i) and appends 32
+        b, _, h, w = x.shape
+        buf = x.new_empty((b, self.cout, h, w))
+        buf[:, : self.cin] = x
+        c = self.cin
+        for layer in self.values():
+            buf[:, c: c + GROWTH] = layer(buf[:, :c])
+            c += GROWTH
+        return buf
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(cin)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(cin, cout, kernel_size=1, stride=1, bias=False)
+        self.pool = nn.AvgPool2d(kernel_size=2, stride=2)
+
+
+def _make_features():
+    layers = OrderedDict()
+    layers["conv0"] = nn.Conv2d(3, INIT_FEATURES, kernel_size=7, stride=2, padding=3, bias=False)
+    layers["norm0"] = nn.BatchNorm2d(INIT_FEATURES)
+    layers["relu0"] = nn.ReLU(inplace=True)
+    layers["pool0"] = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    c = INIT_FEATURES
+    for i, n in enumerate(BLOCK_CONFIG):
+        blk = _DenseBlock(n, c)
+        layers[f"denseblock{i + 1}"] = blk
+        c = blk.cout
+        if i != len(BLOCK_CONFIG) - 1:
+            layers[f"transition{i + 1}"] = _Transition(c, c // 2)
+            c //= 2
+    layers["norm5"] = nn.BatchNorm2d(c)
+    feats = nn.Sequential(layers)
+    for m in feats.modules():          # the published initialisation
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+    return feats, c
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift (fp32)."""
+    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class DenseNet121(nn.Module):
+    """Reference model.py:42-84, MI355X-native inference path."""
+
+    def __init__(self, pretrained=False, embedding_dim=None, num_labels=None, weights=None):
+        super().__init__()
+        if pretrained and weights is None:
+            raise RuntimeError("pretrained=True needs a download in the reference (model.py:53); "
+                               "pass weights=<state dict or path> instead")
+        feats, in_features = _make_features()
+        self.densenet121 = nn.Sequential(feats)
+        # reference model.py:59-60: ReLU appended to the feature stack, avgpool to the wrapper
+        self.densenet121[0].add_module("relu", nn.ReLU(inplace=True))
+        self.densenet121.add_module("avgpool", nn.AdaptiveAvgPool2d((1, 1)))
+        self.fc = nn.Linear(in_features, embedding_dim) if embedding_dim else None
+        out_features = embedding_dim if embedding_dim else in_features
+        self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
+        self.use_hip_stem = True
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            for key in ("state-dict", "state_dict"):      # wrappers test.py:1273-1276 accepts
+                if isinstance(sd, dict) and key in sd:
+                    sd = sd[key]
+            self.load_state_dict(sd, strict=False)
+
+    # -- the plain module graph (training, CPU tensors): same ops as the reference -------------
+    def forward_eager(self, x):
+        x = self.densenet121(x)
+        return torch.flatten(x, 1)
+
+    # -- MI355X inference path -------------------------------------------------------------------
+    def _features_fused(self, x):
+        """-> (feature map before norm5 [B,1024,h,w])"""
+        f = self.densenet121[0]
+        lib = _lib.load()
+        x = x.contiguous().float()
+        b, _, h, w = x.shape
+        if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
+            sc, sh = _bn_affine(f.norm0)
+            y = torch.empty((b, INIT_FEATURES, h // 4, w // 4), dtype=torch.float32, device=x.device)
+            wt = f.conv0.weight.detach().float().contiguous()
+            _lib.check(lib.mirx_stem_conv7_bn_relu_pool(_ptr(x), _ptr(wt), _ptr(sc), _ptr(sh), b, h, w,
+                                                        _ptr(y), _stream(x.device)), "mirx_stem")
+            x = y
+        else:
+            x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
+        for name, m in f.named_children():
+            if name.startswith("denseblock") or name.startswith("transition"):
+                x = m(x)
+        return x
+
+    def _head_fused(self, fmap, normalize):
+        f = self.densenet121[0]
+        lib = _lib.load()
+        sc, sh = _bn_affine(f.norm5)
+        fmap = fmap.contiguous()
+        b, c, h, w = fmap.shape
+        out = torch.empty((b, c), dtype=torch.float32, device=fmap.device)
+        _lib.check(lib.mirx_bn_relu_gap_l2norm(_ptr(fmap), _ptr(sc), _ptr(sh), b, c, h * w,
+                                               1 if normalize else 0, _ptr(out), _stream(fmap.device)),
+                   "mirx_bn_relu_gap_l2norm")
+        return out
+
+    def forward(self, x):
+        fused = x.is_cuda and not self.training and not torch.is_grad_enabled()
+        if fused:
+            with torch.cuda.device(x.device):
+                fmap = self._features_fused(x)
+                plain_head = self.fc is None and self.classification_head is None
+                x = self._head_fused(fmap, normalize=plain_head)
+                if plain_head:
+                    return x                       # already unit-norm (model.py:83)
+        else:
+            x = self.forward_eager(x)
+        if self.fc:
+            x = self.fc(x)
+        if self.classification_head is not None:
+            return {"embedding": F.normalize(x, dim=1), "logits": self.classification_head(x)}
+        return F.normalize(x, dim=1)
+
+
+def build_model(model_type, embedding_dim=None, **kw):
+    """Factory in the spirit of milvus_retrieval.py:143-162 (unknown type -> ValueError)."""
+    if model_type == "densenet121":
+        return DenseNet121(embedding_dim=embedding_dim, **kw), 224
+    raise ValueError(f"Unknown model type: {model_type}")

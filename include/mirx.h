@@ -54,6 +54,15 @@ extern "C" {
 #define MIRX_OPT_TIERS 1
 #define MIRX_OPT_SAMPLE_RANK 2   /* j: threshold = j-th largest sampled group maximum (default 8)  */
 #define MIRX_OPT_FORCE_TAU 3     /* test hook: float bits of a fixed threshold; 0x7fc00000 = off  */
+#define MIRX_OPT_PROFILE 4       /* 1: record HIP events around every stage of a search           */
+
+/* stages timed when MIRX_OPT_PROFILE is on (mirx_index_last_timings) */
+#define MIRX_STAGE_PREP 0        /* query conversion                                  */
+#define MIRX_STAGE_SAMPLE 1      /* group-max GEMM on the row sample + threshold pick */
+#define MIRX_STAGE_GEMM 2        /* the filter GEMM over the whole gallery            */
+#define MIRX_STAGE_FINALIZE 3    /* candidate sort, guard, fp64 re-rank               */
+#define MIRX_STAGE_EXACT 4       /* exact scan of rejected / routed queries           */
+#define MIRX_NUM_STAGES 5
 
 typedef struct mirx_index mirx_index;
 
@@ -118,6 +127,14 @@ int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
 
 /* Waits for `stream`, then copies the counters of the last search. */
 int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out);
+
+/*
+ * Device time of each stage of the last search in milliseconds, measured with HIP events
+ * recorded on the search's own stream (needs MIRX_OPT_PROFILE = 1 before the search; stages
+ * that did not run report 0; a search split into several internal passes reports sums).
+ * out_ms: host array of MIRX_NUM_STAGES floats.
+ */
+int mirx_index_last_timings(mirx_index *ix, float *out_ms);
 
 /*
  * Full ranking of every gallery row for each query (row = query): replaces

@@ -1,0 +1,107 @@
+"""evaluate() drop-in and the Milvus-shaped retriever on the GPU against golden outputs of the
+reference's evaluate() (tests/golden/evaluate_covidx300_d64.npz) and the oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics as OM
+from oracle import search as OS
+
+pytestmark = pytest.mark.gpu
+
+
+class _Lookup(torch.nn.Module):
+    def __init__(self, table):
+        super().__init__()
+        self.register_buffer("table", table)
+
+    def forward(self, idx):
+        return self.table[idx]
+
+
+def test_evaluate_matches_reference_npz(golden_dir, tmp_path, capsys):
+    from mirx.evaluate import evaluate
+    z = np.load(os.path.join(golden_dir, "evaluate_covidx300_d64.npz"))
+    emb, labels = torch.as_tensor(z["embeds"]), torch.as_tensor(z["labels"])
+    loader = [(torch.arange(i, min(i + 64, 300)), labels[i:i + 64]) for i in range(0, 300, 64)]
+    args = types.SimpleNamespace(save_dir=str(tmp_path), resume="ckpt/model_x.pth")
+    res = evaluate(_Lookup(emb).cuda(), loader, torch.device("cuda:0"), args)
+    out = np.load(tmp_path / "model_x.npz")
+    assert set(z.files) == set(out.files)
+    np.testing.assert_array_equal(out["embeds"], z["embeds"])
+    np.testing.assert_array_equal(out["labels"], z["labels"])
+    np.testing.assert_array_equal(out["kappas"], z["kappas"])
+    np.testing.assert_array_equal(out["classification_k_values"], z["classification_k_values"])
+    # the ranking is the fp64 oracle's; the reference's fp32 cdist/argsort flips 1/300 near-tie
+    ranks = OS.rank_all(z["embeds"], z["embeds"], metric=OS.METRIC_NEG_L2, exclude=np.arange(300))
+    np.testing.assert_array_equal(res["ranks"].cpu().numpy(), ranks)
+    mAP, _, pr, _ = OM.compute_map(ranks.T, z["labels"], [1, 5, 10])
+    assert float(out["mAP"]) == pytest.approx(mAP, abs=1e-12)
+    np.testing.assert_allclose(out["pr"], pr, atol=1e-12)
+    assert float(out["mAP"]) == pytest.approx(float(z["mAP"]), abs=2e-4)
+    np.testing.assert_allclose(out["pr"], z["pr"], atol=4 / 300)
+    np.testing.assert_allclose(out["acc"], z["acc"], atol=1.0)
+    for k in (1, 5, 10, 15, 20):
+        np.testing.assert_allclose(out[f"classification_k{k}"], z[f"classification_k{k}"], atol=1.0)
+    # dists: +L2 with +inf diagonal, same as the reference's saved matrix up to fp32 rounding
+    assert np.all(np.isposinf(np.diag(out["dists"])))
+    off = ~np.eye(300, dtype=bool)
+    np.testing.assert_allclose(out["dists"][off], z["dists"][off], atol=2e-5)
+    text = capsys.readouterr().out
+    assert ">> R@K[1, 5, 10]:" in text and ">> mAP:" in text and ">> Top-20 Retrieved Images:" in text
+
+
+def test_retriever_protocol(tmp_path):
+    from PIL import Image
+    from mirx.retriever import MilvusManager, MilvusRetriever, default_transform, search_collection
+    mgr = MilvusManager(dataset="covid")
+    assert mgr.connect() is True
+    with pytest.raises(ValueError):
+        mgr.create_collection("nope")
+    with pytest.raises(ValueError):
+        mgr.load_collection("densenet121")                     # does not exist yet
+    col = mgr.create_collection("densenet121", drop_old=True)
+    assert col.name == "covid_image_retrieval_densenet121"
+    mgr.create_index("densenet121", metric_type="COSINE")
+    g = torch.nn.functional.normalize(torch.randn(500, 1024, generator=torch.Generator().manual_seed(1)), dim=1)
+    paths = [f"/data/img_{i}.png" for i in range(500)]
+    labels = [["normal", "pneumonia", "COVID-19"][i % 3] for i in range(500)]
+    for s in range(0, 500, 100):                                 # ingest_embeddings.py:399-411 batches of 100
+        col.insert([paths[s:s + 100], labels[s:s + 100], g[s:s + 100].numpy().tolist()])
+    col.flush()
+    assert mgr.get_collection_info("densenet121")["num_entities"] == 500
+
+    class _Fake(torch.nn.Module):                                # embeds an image to a fixed gallery row
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            idx = (x.flatten(1).abs().sum(1) * 0).long() + 7
+            return g.to(x.device)[idx] * 3.0                     # un-normalised on purpose
+
+    img = Image.fromarray((np.random.default_rng(0).random((300, 260, 3)) * 255).astype(np.uint8))
+    p = tmp_path / "q.png"
+    img.save(p)
+    tf = default_transform(224)
+    assert tf(img).shape == (3, 224, 224)
+    r = MilvusRetriever(mgr, "densenet121", _Fake().cuda(), tf)
+    r.load_collection()
+    results, qemb = r.search(str(p), top_k=5, metric_type="COSINE")
+    assert qemb.shape == (1, 1024) and qemb.is_cuda
+    assert [set(d) for d in results][0] == {"id", "image_path", "label", "distance", "similarity"}
+    assert results[0]["id"] == 7 and results[0]["image_path"] == "/data/img_7.png" and results[0]["label"] == labels[7]
+    assert results[0]["distance"] == pytest.approx(1.0, abs=1e-6) and results[0]["similarity"] == results[0]["distance"]
+    o_s, o_i = OS.topk(g[7:8].numpy(), g.numpy(), 5)
+    assert [d["id"] for d in results] == o_i[0].tolist()
+    assert [d["distance"] for d in results] == pytest.approx(o_s[0].tolist(), abs=1e-6)
+    batch = r.batch_search([str(p), img], top_k=3)
+    assert len(batch) == 2 and [d["id"] for d in batch[0]] == o_i[0][:3].tolist()
+    hits = search_collection(col, g[3].tolist(), top_k=4)
+    assert hits[0]["id"] == 3 and "score" in hits[0] and hits[0]["image_path"] == "/data/img_3.png"
+    with pytest.raises(ValueError):
+        col.insert([["a"], ["b"], [[0.0] * 7]])
+    mgr.disconnect()
