@@ -77,11 +77,11 @@ def build_shard(index, lo, hi, dim, device, chunk=1 << 16):
 
 
 def cpu_baseline(index, model, args, dev):
-    """Reference CPU path on a bounded sample: embed 16 images + cdist/topk of 32 queries."""
+    """Reference CPU path on a bounded sample: embed 64 images (B=64, test.py:1513) + cdist/topk of 32 queries."""
     from oracle import densenet as OD
     nthreads = torch.get_num_threads()
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    imgs = synthetic_images(16, args.image_size, 777, dev).cpu()
+    imgs = synthetic_images(64, args.image_size, 777, dev).cpu()
     with torch.no_grad():
         OD.embed(imgs[:2], sd)
         t0 = time.perf_counter()
@@ -100,7 +100,7 @@ def cpu_baseline(index, model, args, dev):
         d.topk(args.k, 1, True, True)
         t_search = (time.perf_counter() - t0) / q.shape[0]
     return {"value": 1.0 / (t_embed + t_search), "unit": "queries/s", "cores": nthreads, "kind": "port",
-            "sample": f"16 images embedded (oracle DenseNet-121 fp32, {1.0 / t_embed:.1f} img/s) + 32 queries "
+            "sample": f"64 images embedded (oracle DenseNet-121 fp32, {1.0 / t_embed:.1f} img/s) + 32 queries "
                       f"-torch.cdist+topk({args.k}) over {len(index)}x{args.dim} fp32 ({1.0 / t_search:.1f} q/s); "
                       f"torch CPU threads={nthreads}, os.cpu_count={os.cpu_count()}"}
 

@@ -55,6 +55,8 @@ SYMBOLS = {
     "mirx_topk_merge": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "mirx_bn_relu_nchw": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
 }
 

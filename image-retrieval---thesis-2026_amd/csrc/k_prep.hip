@@ -7,6 +7,8 @@
 // All kernels: one 64-lane wave per row, 16-byte loads, wave-shuffle reductions.
 #include "mirx_kernels.h"
 
+#include <algorithm>
+
 namespace mirx {
 
 namespace {
@@ -135,7 +137,77 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
     }
 }
 
+// relu(x*scale+shift) over the channel-prefix slab of each image: the slab [c*hw] is contiguous,
+// so lanes stream it with 16-B loads; the channel of an element is e / hw.
+__global__ __launch_bounds__(256) void k_bn_relu(const float *__restrict__ x, int64_t xbs,
+                                                 const float *__restrict__ scale,
+                                                 const float *__restrict__ shift, int c, int hw,
+                                                 float *__restrict__ y) {
+    const int64_t b = blockIdx.y;
+    const int64_t slab = (int64_t)c * hw;                 // multiple of 4 (checked by the launcher)
+    const float *xb = x + b * xbs;
+    float *yb = y + b * slab;
+    const float inv_hw = 1.0f / (float)hw;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < slab; e += (int64_t)gridDim.x * 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(xb + e);
+        int ch = (int)((float)e * inv_hw);                // estimate, then fix up by at most one
+        while ((int64_t)(ch + 1) * hw <= e) ++ch;
+        while ((int64_t)ch * hw > e) --ch;
+        float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+        int64_t next = (int64_t)(ch + 1) * hw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (e + j >= next) { ++ch; next += hw; }
+            out[j] = fmaxf(fmaf(in[j], scale[ch], shift[ch]), 0.0f);
+        }
+        *reinterpret_cast<float4 *>(yb + e) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// avgpool2x2(relu(bn(x))): one thread per pair of horizontally adjacent outputs.
+__global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restrict__ x, int64_t xbs,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int c, int h,
+                                                          int w, float *__restrict__ y) {
+    const int64_t b = blockIdx.z;
+    const int ch = blockIdx.y;
+    const int oh = h >> 1, ow = w >> 1;
+    const float sc = scale[ch], sh = shift[ch];
+    const float *xp = x + b * xbs + (int64_t)ch * h * w;
+    float *yp = y + (b * c + ch) * (int64_t)oh * ow;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < oh * ow; o += gridDim.x * 256) {
+        const int oy = o / ow, ox = o % ow;
+        const float2 r0 = *reinterpret_cast<const float2 *>(xp + (int64_t)(2 * oy) * w + 2 * ox);
+        const float2 r1 = *reinterpret_cast<const float2 *>(xp + (int64_t)(2 * oy + 1) * w + 2 * ox);
+        const float s = fmaxf(fmaf(r0.x, sc, sh), 0.0f) + fmaxf(fmaf(r0.y, sc, sh), 0.0f) +
+                        fmaxf(fmaf(r1.x, sc, sh), 0.0f) + fmaxf(fmaf(r1.y, sc, sh), 0.0f);
+        yp[o] = s * 0.25f;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale,
+                               const float *shift, int64_t n, int c, int hw, float *y, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t slab = (int64_t)c * hw;
+    if ((slab & 3) || (x_batch_stride & 3) || n > 65535) return hipErrorInvalidValue;
+    const unsigned gx = (unsigned)std::min<int64_t>((slab / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_bn_relu, dim3(gx, (unsigned)n), dim3(256), 0, st, x, x_batch_stride, scale, shift,
+                       c, hw, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
+                                   const float *shift, int64_t n, int c, int h, int w, float *y,
+                                   hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if ((h & 1) || (w & 1) || (x_batch_stride & 1) || n > 65535 || c > 65535) return hipErrorInvalidValue;
+    const int outs = (h / 2) * (w / 2);
+    hipLaunchKernelGGL(k_bn_relu_avgpool2, dim3((unsigned)((outs + 255) / 256), (unsigned)c, (unsigned)n),
+                       dim3(256), 0, st, x, x_batch_stride, scale, shift, c, h, w, y);
+    return hipGetLastError();
+}
 
 hipError_t launch_ingest(const float *src, int64_t n, int dim, int dimp, float *g32,
                          uint16_t *g16, float *gbias, unsigned *gnorm_max_bits, int metric,

@@ -577,6 +577,26 @@ int mirx_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shi
     return MIRX_OK;
 }
 
+int mirx_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
+                      int64_t n, int c, int hw, float *y, void *stream) {
+    MIRX_CHECK(x && scale && shift && y && n >= 0 && c >= 1 && hw >= 1, "bn_relu_nchw: bad argument");
+    MIRX_CHECK(((int64_t)c * hw) % 4 == 0 && x_batch_stride % 4 == 0 && x_batch_stride >= (int64_t)c * hw,
+               "bn_relu_nchw: c*hw and the batch stride must be multiples of 4");
+    MIRX_HIP(launch_bn_relu_nchw(x, x_batch_stride, scale, shift, n, c, hw, y,
+                                 reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
+                          int64_t n, int c, int h, int w, float *y, void *stream) {
+    MIRX_CHECK(x && scale && shift && y && n >= 0 && c >= 1, "bn_relu_avgpool2: bad argument");
+    MIRX_CHECK(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && x_batch_stride % 2 == 0,
+               "bn_relu_avgpool2: h, w and the batch stride must be even");
+    MIRX_HIP(launch_bn_relu_avgpool2(x, x_batch_stride, scale, shift, n, c, h, w, y,
+                                     reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *scale, const float *shift,
                                  int64_t n, int h, int wd, float *y, void *stream) {
     MIRX_CHECK(x && w && scale && shift && y && n >= 0, "stem: null argument");

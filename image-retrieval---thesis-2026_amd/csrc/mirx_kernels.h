@@ -18,6 +18,11 @@ hipError_t launch_l2_normalize(float *x, int64_t n, int dim, hipStream_t st);
 hipError_t launch_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shift,
                                      int64_t n, int c, int hw, int normalize, float *y,
                                      hipStream_t st);
+hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale,
+                               const float *shift, int64_t n, int c, int hw, float *y, hipStream_t st);
+hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
+                                   const float *shift, int64_t n, int c, int h, int w, float *y,
+                                   hipStream_t st);
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 

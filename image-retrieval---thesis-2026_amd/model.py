@@ -16,8 +16,11 @@ feature parameters, final map [B,1024,H/32,W/32].
 
 MI355X path (CUDA tensors, eval mode):
   * stem conv0+norm0+relu0+pool0 -> one HIP kernel (libmirx ``mirx_stem_conv7_bn_relu_pool``)
-  * dense blocks run under PyTorch-ROCm; each block owns ONE preallocated feature buffer and
-    every layer writes its 32 new channels into it (no O(L^2) torch.cat re-copies)
+  * dense blocks: convolutions run under PyTorch-ROCm (MIOpen / rocBLAS, fp32); each block owns
+    ONE preallocated feature buffer (no O(L^2) torch.cat re-copies); norm1+relu1 is one HIP pass
+    over the buffer's channel prefix (``mirx_bn_relu_nchw``); norm2 is folded into conv1
+  * transitions: norm+relu+avgpool in one HIP pass (``mirx_bn_relu_avgpool2``), then the 1x1
+    conv on the pooled map (conv and average pool commute)
   * norm5+relu+global-average-pool+flatten+F.normalize -> one HIP kernel
     (``mirx_bn_relu_gap_l2norm``), or GAP only when an ``fc`` follows.
 ``pretrained=True`` would need a download in the reference (model.py:53); here it raises
@@ -74,6 +77,49 @@ class _DenseBlock(nn.ModuleDict):
             buf[:, c: c + GROWTH] = layer(buf[:, :c])
             c += GROWTH
         return buf
+
+
+def _fused_bn_relu(lib, buf, c, scale, shift):
+    """relu(bn(buf[:, :c])) -> packed [B, c, H, W] in one HIP pass over the channel-prefix view."""
+    b, ctot, h, w = buf.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=buf.device)
+    _lib.check(lib.mirx_bn_relu_nchw(_ptr(buf), ctot * h * w, _ptr(scale), _ptr(shift), b, c, h * w,
+                                     _ptr(out), _stream(buf.device)), "mirx_bn_relu_nchw")
+    return out
+
+
+def _dense_block_fused(block, x, cache):
+    """Inference path of one dense block (CUDA, eval):
+       per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2 folded into its
+       weights/bias) -> relu2 in place -> conv2 (3x3) -> 32 new channels copied into the buffer."""
+    lib = _lib.load()
+    b, _, h, w = x.shape
+    buf = torch.empty((b, block.cout, h, w), dtype=torch.float32, device=x.device)
+    buf[:, : block.cin] = x
+    c = block.cin
+    for name, layer in block.items():
+        sc1, sh1, w1, b1 = cache[name]
+        y = _fused_bn_relu(lib, buf, c, sc1, sh1)
+        y = F.conv2d(y, w1, b1)
+        y = F.conv2d(F.relu_(y), layer.conv2.weight, None, padding=1)
+        buf[:, c: c + GROWTH] = y
+        c += GROWTH
+    return buf
+
+
+def _transition_fused(tr, buf, cache):
+    """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
+    the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
+    lib = _lib.load()
+    sc, sh = cache
+    b, c, h, w = buf.shape
+    if h % 2 or w % 2:
+        return tr.pool(tr.conv(F.relu(F.batch_norm(buf, tr.norm.running_mean, tr.norm.running_var,
+                                                   tr.norm.weight, tr.norm.bias, False, 0.0, tr.norm.eps))))
+    pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
+    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled),
+                                         _stream(buf.device)), "mirx_bn_relu_avgpool2")
+    return F.conv2d(pooled, tr.conv.weight)
 
 
 class _Transition(nn.Sequential):
@@ -142,6 +188,7 @@ class DenseNet121(nn.Module):
         out_features = embedding_dim if embedding_dim else in_features
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
+        self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             for key in ("state-dict", "state_dict"):      # wrappers test.py:1273-1276 accepts
@@ -155,14 +202,48 @@ class DenseNet121(nn.Module):
         return torch.flatten(x, 1)
 
     # -- MI355X inference path -------------------------------------------------------------------
+    def train(self, mode=True):
+        self._infer_cache = None
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **k):
+        self._infer_cache = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._infer_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def _prepare_inference(self):
+        """Fold every eval-mode BatchNorm once: norm1/transition norm -> (scale, shift) for the
+        fused HIP passes; norm2 -> into conv1's weights and bias."""
+        f = self.densenet121[0]
+        cache = {}
+        for name, m in f.named_children():
+            if name.startswith("denseblock"):
+                blk = {}
+                for lname, layer in m.items():
+                    sc1, sh1 = _bn_affine(layer.norm1)
+                    sc2, sh2 = _bn_affine(layer.norm2)
+                    w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
+                    blk[lname] = (sc1, sh1, w1, sh2)
+                cache[name] = blk
+            elif name.startswith("transition"):
+                cache[name] = _bn_affine(m.norm)
+        cache["norm0"] = _bn_affine(f.norm0)
+        cache["norm5"] = _bn_affine(f.norm5)
+        self._infer_cache = cache
+        return cache
+
     def _features_fused(self, x):
         """-> (feature map before norm5 [B,1024,h,w])"""
         f = self.densenet121[0]
         lib = _lib.load()
         x = x.contiguous().float()
         b, _, h, w = x.shape
+        cache = self._infer_cache or self._prepare_inference()
         if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
-            sc, sh = _bn_affine(f.norm0)
+            sc, sh = cache["norm0"]
             y = torch.empty((b, INIT_FEATURES, h // 4, w // 4), dtype=torch.float32, device=x.device)
             wt = f.conv0.weight.detach().float().contiguous()
             _lib.check(lib.mirx_stem_conv7_bn_relu_pool(_ptr(x), _ptr(wt), _ptr(sc), _ptr(sh), b, h, w,
@@ -171,14 +252,16 @@ class DenseNet121(nn.Module):
         else:
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
         for name, m in f.named_children():
-            if name.startswith("denseblock") or name.startswith("transition"):
-                x = m(x)
+            if name.startswith("denseblock"):
+                x = _dense_block_fused(m, x, cache[name])
+            elif name.startswith("transition"):
+                x = _transition_fused(m, x, cache[name])
         return x
 
     def _head_fused(self, fmap, normalize):
         f = self.densenet121[0]
         lib = _lib.load()
-        sc, sh = _bn_affine(f.norm5)
+        sc, sh = (self._infer_cache or self._prepare_inference())["norm5"]
         fmap = fmap.contiguous()
         b, c, h, w = fmap.shape
         out = torch.empty((b, c), dtype=torch.float32, device=fmap.device)

@@ -173,6 +173,23 @@ int mirx_bn_relu_gap_l2norm(const float *x, const float *scale, const float *shi
                             int c, int hw, int normalize, float *y, void *stream);
 
 /*
+ * y = relu(x * scale[c] + shift[c]) for the first c channels of an NCHW fp32 tensor whose
+ * images are `x_batch_stride` floats apart (a channel-prefix view of a wider dense-block
+ * buffer); y is packed [n, c, hw].  Replaces norm1 -> relu1 (and transition norm -> relu) of
+ * torchvision's _DenseLayer / _Transition (model.py:53) in ONE pass instead of two.
+ */
+int mirx_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
+                      int64_t n, int c, int hw, float *y, void *stream);
+
+/*
+ * Transition front half: y = avgpool2x2(relu(x * scale[c] + shift[c])), x as above with
+ * h x w pixels (h, w even), y packed [n, c, h/2, w/2].  The 1x1 transition conv commutes with
+ * the average pool, so the caller runs it on the pooled map (4x fewer pixels).
+ */
+int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
+                          const float *shift, int64_t n, int c, int h, int w, float *y, void *stream);
+
+/*
  * DenseNet stem: conv 7x7 stride 2 pad 3 (3 -> 64 channels) + folded BatchNorm + ReLU +
  * max-pool 3x3 stride 2 pad 1, NCHW fp32 in, NCHW fp32 out [n, 64, H/4, W/4].
  * Replaces features.conv0/norm0/relu0/pool0 of torchvision densenet121 (model.py:53).

@@ -82,3 +82,30 @@ def test_embeddings_match_cpu_restatement(model_and_sd):
     with torch.no_grad():
         out = m2(x[:2].cuda())
     assert out["embedding"].shape == (2, 256) and out["logits"].shape == (2, 3)
+
+
+def test_fused_elementwise_kernels():
+    import ctypes
+    from mirx import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    for (b, ctot, c, h, w) in ((3, 256, 96, 56, 56), (2, 1024, 992, 7, 7), (2, 64, 64, 14, 14)):
+        buf = torch.randn(b, ctot, h, w, generator=g)
+        sc = 0.5 + torch.rand(c, generator=g)
+        sh = 0.3 * torch.randn(c, generator=g)
+        want = torch.relu(buf[:, :c] * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        bg, scg, shg = buf.cuda(), sc.cuda(), sh.cuda()
+        y = torch.empty((b, c, h, w), device="cuda")
+        assert lib.mirx_bn_relu_nchw(ctypes.c_void_p(bg.data_ptr()), ctot * h * w, ctypes.c_void_p(scg.data_ptr()),
+                                     ctypes.c_void_p(shg.data_ptr()), b, c, h * w,
+                                     ctypes.c_void_p(y.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.cpu(), want, atol=1e-6, rtol=1e-6)
+        if h % 2 == 0:
+            want_p = torch.nn.functional.avg_pool2d(want, 2, 2)
+            yp = torch.empty((b, c, h // 2, w // 2), device="cuda")
+            assert lib.mirx_bn_relu_avgpool2(ctypes.c_void_p(bg.data_ptr()), ctot * h * w,
+                                             ctypes.c_void_p(scg.data_ptr()), ctypes.c_void_p(shg.data_ptr()),
+                                             b, c, h, w, ctypes.c_void_p(yp.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            torch.testing.assert_close(yp.cpu(), want_p, atol=1e-6, rtol=1e-6)

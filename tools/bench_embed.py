@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Embed-only micro benchmark (development tool): DenseNet-121 images/s on one GPU."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mirx.model import DenseNet121  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-hip-stem", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = DenseNet121().eval().to(dev)
+    m.use_hip_stem = not a.no_hip_stem
+    if a.channels_last:
+        m = m.to(memory_format=torch.channels_last)
+    x = torch.randn(a.batch, 3, a.size, a.size, device=dev)
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            y = m(x)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    print(f"B={a.batch} {a.size}x{a.size}: {dt*1e3:.1f} ms/batch, {a.batch/dt:.0f} img/s")
+
+
+if __name__ == "__main__":
+    main()
