@@ -92,8 +92,7 @@ def cpu_baseline(index, model, args, dev):
     for s in range(0, len(index), step):
         rows, _ = index.rows(s, min(step, len(index) - s))
         g_host[s:s + rows.shape[0]] = rows.cpu()
-    q = torch.nn.functional.normalize(torch.randn(32, args.dim, generator=torch.Generator().manual_seed(4321)), dim=1)
-    q[: emb.shape[0]] = emb
+    q = emb[:32].contiguous()                      # the embeddings just computed are the queries
     with torch.no_grad():
         t0 = time.perf_counter()
         d = -torch.cdist(q, g_host)
