@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirx.so")
+LIB_PATH = os.environ.get("MIRX_LIB_PATH", os.path.join(_HERE, "libmirx.so"))   # override: kernel experiments only
 
 METRIC_IP = 0
 METRIC_NEG_L2 = 1

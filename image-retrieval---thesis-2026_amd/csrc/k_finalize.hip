@@ -75,20 +75,38 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
     __shared__ float sh_lo;
     const int qi = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int c_raw = A.cnt[qi];
-    const bool overflow = c_raw > CAND_CAP;
-    const int c = overflow ? CAND_CAP : c_raw;
+    // gather the producer regions (+ the shared overflow list) of this query into `keys`
+    __shared__ int sh_cnt, sh_raw, sh_ovf;
+    if (threadIdx.x == 0) { sh_cnt = 0; sh_raw = 0; sh_ovf = 0; }
+    for (int i = threadIdx.x; i < CAND_CAP; i += 256) keys[i] = 0ull;
+    __syncthreads();
+    auto push = [&](const Cand cd) {
+        const int p = atomicAdd(&sh_cnt, 1);
+        if (p < CAND_CAP)
+            keys[p] = ((unsigned long long)f32_orderable(cd.s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)cd.row);
+    };
+    for (int rg = threadIdx.x; rg < A.regions; rg += 256) {
+        const int cr = A.region_cnt[(int64_t)qi * A.regions + rg];
+        if (cr > 0) {
+            atomicAdd(&sh_raw, cr);
+            const int take = cr < A.slots ? cr : A.slots;
+            const Cand *src = A.cand + ((int64_t)qi * A.regions + rg) * A.slots;
+            for (int i = 0; i < take; ++i) push(src[i]);
+        }
+    }
+    {
+        const int oc = A.ovf_cnt[qi];
+        if (oc > CAND_OVF && threadIdx.x == 0) sh_ovf = 1;         // overflow list itself overflowed
+        const int take = oc < CAND_OVF ? oc : CAND_OVF;
+        for (int i = threadIdx.x; i < take; i += 256) push(A.ovf[(int64_t)qi * CAND_OVF + i]);
+    }
+    __syncthreads();
+    const int c_raw = sh_raw;
+    const bool overflow = sh_cnt > CAND_CAP || sh_ovf != 0;
+    const int c = sh_cnt > CAND_CAP ? CAND_CAP : sh_cnt;
     const int64_t ex = A.exclude ? A.exclude[qi] : -1;
     const int k_eff = A.k + (ex >= 0 ? 1 : 0);
     const int m2 = pow2_ceil(c > 1 ? c : 1);
-    for (int i = threadIdx.x; i < m2; i += 256) {
-        unsigned long long key = 0ull;
-        if (i < c) {
-            const Cand cd = A.cand[(int64_t)qi * CAND_CAP + i];
-            key = ((unsigned long long)f32_orderable(cd.s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)cd.row);
-        }
-        keys[i] = key;
-    }
     bitonic_lds(keys, m2, [](unsigned long long x, unsigned long long y) { return x > y; });
     if (threadIdx.x == 0) {
         int ok = (!overflow && c >= k_eff) ? 1 : 0;

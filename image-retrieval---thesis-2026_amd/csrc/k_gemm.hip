@@ -12,10 +12,19 @@
 // test is one running max per lane and one compare, ~0.5 VALU per score.
 //
 // Tile: 256 gallery rows x BN queries (BN = 64/128/256), BK = 64, 8 waves (512 threads),
-// v_mfma_f32_32x32x16_bf16, LDS double buffer filled by global_load_lds_dwordx4 (16 B per
-// lane, wave-linear LDS image).  Bank conflicts: rows are 128 B; the 16-B chunk index is
-// XORed with (row >> 1) & 7 on the SOURCE address and on the ds_read_b128 address, which
-// makes every 16-lane ds_read_b128 group hit 16 distinct slots (DESIGN.md "LDS image").
+// v_mfma_f32_32x32x16_bf16, LDS double buffer filled by `buffer_load_dwordx4 ... lds` (16 B per
+// lane, wave-linear LDS image; one per-lane voffset for the whole kernel, everything else of the
+// address is scalar).  Bank conflicts: tile rows are 128 B; the 16-B chunk index is XORed with
+// (row >> 1) & 7 on the SOURCE address and on the ds_read_b128 address, which makes every
+// 16-lane ds_read_b128 group hit 16 distinct slots (DESIGN.md "LDS image").
+//
+// K loop (one barrier per K-step, LDS latency hidden inside the wave):
+//   * DMA of tile kt+2 is issued right after the barrier that ends tile kt's LDS reads;
+//   * fragments roll: the A fragment of row-tile mi is re-read (next k-slice) right after the
+//     two MFMAs that consume it have issued; B fragments are double-buffered; so every ds_read
+//     has several MFMAs of cover before its first use;
+//   * the barrier sits in front of the LAST slice of a tile: that slice's fragments are already
+//     in registers, so its MFMAs cover the DMA issue and the first reads of tile kt+1.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -30,28 +39,74 @@ constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;             // 128 B of K per tile row
 constexpr int A_TILE_BYTES = BM * ROW_BYTES;  // 32 KiB
 
+// Diagnostic builds (results wrong; used to attribute time, see DESIGN.md "GEMM time attribution")
+#ifdef MIRX_EXP_NODMA   // no DMA after the first two K-tiles
+#define MIRX_EXP_COND && (A.dimp < 0)
+#else
+#define MIRX_EXP_COND
+#endif
+#ifdef MIRX_EXP_NOBAR   // no workgroup barrier in the K loop
+#define MIRX_KBARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define MIRX_KBARRIER() __syncthreads()
+#endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
-// Stage `rows` tile rows (rows % 64 == 0) of a K-contiguous bf16 matrix into LDS.
-// Wave w issues pieces w, w+8, ...; piece = 64 lanes x 16 B = 8 tile rows.
+// Stage ROWS tile rows of a K-contiguous bf16 matrix into LDS through a buffer descriptor.
+// Wave w issues pieces w, w+8, ...; piece = 64 lanes x 16 B = 8 tile rows.  `voff` is the
+// per-lane byte offset of (row-in-piece-group, swizzled chunk); `soff0` the scalar byte offset
+// of (tile row 0, k0); `piece_stride` the bytes between rows 64 apart.
 template <int ROWS>
-__device__ inline void stage_tile(char *lds_tile, const uint16_t *__restrict__ src, int64_t row0,
-                                  int64_t row_step, int64_t ld_elems, int k0, int wave, int lane) {
+__device__ inline void stage_tile(char *lds_tile, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff0,
+                                  int piece_stride, int wave) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        const int piece = i * 8 + wave;
-        const int p = piece * 64 + lane;          // 16-B slot in the tile image
-        const int row = p >> 3;
-        const int chunk = (p & 7) ^ ((row >> 1) & 7);
-        const uint16_t *g = src + (row0 + (int64_t)row * row_step) * ld_elems + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < ROWS / 64; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (i * 8 + wave) * 1024), 16, voff,
+                                                 soff0 + i * piece_stride, 0, 0);
 }
 
-__device__ inline bf16x8 lds_frag(const char *lds_tile, int row, int chunk) {
-    const int off = row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
-    return *reinterpret_cast<const bf16x8 *>(lds_tile + off);
+// ---- the persistent schedule, shared by the kernel and by gemm_plan() on the host --------------
+// A workgroup is bound to ONE query tile for its whole life and walks the gallery tiles
+// ph, ph + nph, ph + 2 nph, ...   ("unit" = (query tile, phase ph)).  Units are numbered
+// query group (4 tiles) > phase > tile in group and dealt to workgroups so that unit U runs on XCD
+// label U / (grid/8): the 32 workgroups of an XCD label then share 4 query tiles (2 MiB, L2
+// resident) and stream 8 gallery tiles at a time.  Speed only -- any assignment is correct.
+struct Plan {
+    int64_t ngt;     // gallery tiles
+    int nqt;         // query tiles
+    int nph;         // phases (= producer workgroups) per query tile
+    int grid;        // workgroups launched (multiple of 8)
+    __host__ __device__ int units() const { return nqt * nph; }
+    __host__ __device__ void unit(int u, int &qt, int &ph) const {
+        const int full_groups = nqt / 4, per_group = 4 * nph;
+        if (u < full_groups * per_group) {
+            const int g = u / per_group, l = u % per_group;
+            ph = l >> 2;
+            qt = g * 4 + (l & 3);
+        } else {
+            const int l = u - full_groups * per_group, gsz = nqt - 4 * full_groups;
+            ph = l / gsz;
+            qt = full_groups * 4 + l % gsz;
+        }
+    }
+};
+
+__host__ __device__ inline Plan make_plan(int64_t n_rows, int64_t nq_pad, int bn, int grid_cap) {
+    Plan p;
+    p.ngt = (n_rows + BM - 1) / BM;
+    p.nqt = (int)(nq_pad / bn);
+    int nph = p.nqt > 0 ? grid_cap / p.nqt : 1;
+    if (nph < 1) nph = 1;
+    if (nph > p.ngt) nph = (int)(p.ngt > 0 ? p.ngt : 1);
+    p.nph = nph;
+    p.grid = (p.nqt * nph + 7) / 8 * 8;
+    return p;
+}
+
+// candidate slots of one (query, producer wave) region: about 1024 slots per query in total
+__host__ __device__ inline int region_slots(int regions) {
+    int s = 2048 / (regions > 0 ? regions : 1);
+    return s < 8 ? 8 : (s > 64 ? 64 : s);
 }
 
 // MODE 0: threshold filter.  MODE 1: group maxima of sampled rows.
@@ -63,145 +118,302 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
     constexpr int M_REP = WM_ROWS / 32;
     constexpr int N_REP = 2;
     constexpr int B_TILE_BYTES = BN * ROW_BYTES;
+    constexpr int LDS_B0 = 2 * A_TILE_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const lds_a0 = smem;                          // A buffers: 2 x 32 KiB
-    char *const lds_b0 = smem + 2 * A_TILE_BYTES;       // B buffers: 2 x BN*128 B
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+    const int nk = A.dimp / BK;                   // even (dimp is a multiple of 128)
+    const int ld_bytes = A.dimp * 2;
 
-    const int nqt = (int)(A.nq_pad / BN);
-    const int qt = blockIdx.x % nqt;
-    const int64_t gt = blockIdx.x / nqt;
-    const int64_t g_row0 = gt * BM * A.row_stride;
+    // ---- which unit am I ------------------------------------------------------------------------
+    Plan plan;
+    plan.ngt = (A.n_rows + BM - 1) / BM;
+    plan.nqt = (int)(A.nq_pad / BN);
+    plan.nph = A.nph;
+    plan.grid = gridDim.x;
+    const int u = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (u >= plan.units()) return;
+    int qt, ph;
+    plan.unit(u, qt, ph);
     const int64_t q_row0 = (int64_t)qt * BN;
-    const int nk = A.dimp / BK;
-
-    f32x16 acc[M_REP][N_REP];
-#pragma unroll
-    for (int mi = 0; mi < M_REP; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < N_REP; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    stage_tile<BM>(lds_a0, A.g16, g_row0, A.row_stride, A.dimp, 0, wave, lane);
-    stage_tile<BN>(lds_b0, A.q16, q_row0, 1, A.dimp, 0, wave, lane);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // every wave waits for its own LDS-DMA pieces (vmcnt(0) is emitted by the compiler in
-        // front of the barrier), the barrier then makes all pieces of tile kt visible and
-        // guarantees nobody still reads the buffer that is restaged next.
-        __syncthreads();
-        if (kt + 1 < nk) {
-            stage_tile<BM>(lds_a0 + (cur ^ 1) * A_TILE_BYTES, A.g16, g_row0, A.row_stride, A.dimp,
-                           (kt + 1) * BK, wave, lane);
-            stage_tile<BN>(lds_b0 + (cur ^ 1) * B_TILE_BYTES, A.q16, q_row0, 1, A.dimp, (kt + 1) * BK, wave,
-                           lane);
-        }
-        const char *ta = lds_a0 + cur * A_TILE_BYTES;
-        const char *tb = lds_b0 + cur * B_TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[M_REP], fb[N_REP];
-            const int chunk = kk * 2 + (lane >> 5);
-#pragma unroll
-            for (int mi = 0; mi < M_REP; ++mi)
-                fa[mi] = lds_frag(ta, wm * WM_ROWS + mi * 32 + (lane & 31), chunk);
-#pragma unroll
-            for (int ni = 0; ni < N_REP; ++ni)
-                fb[ni] = lds_frag(tb, wn * 64 + ni * 32 + (lane & 31), chunk);
-#pragma unroll
-            for (int mi = 0; mi < M_REP; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < N_REP; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-        }
+    int *lcnt = reinterpret_cast<int *>(smem + LDS_B0 + 2 * B_TILE_BYTES);   // [BN][WARPS_M] region fill counts
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) lcnt[i] = 0;
     }
 
-    // ---- epilogue -------------------------------------------------------------------------
-    // accumulator register r of tile (mi, ni): gallery row (r&3) + 8*(r>>2) + 4*(lane>>5) of
-    // the 32-row tile, query column lane & 31.
-    const int64_t tile_row0 = gt * BM + wm * WM_ROWS;   // in units of sampled rows
+    // ---- DMA addressing: descriptor per operand tile, one voffset per lane ---------------------
+    const int prow = wave * 8 + (lane >> 3);                       // row inside a 64-row piece group
+    const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);             // source chunk for LDS slot lane&7
+    const int rs = (int)A.row_stride;
+    const int voff_a = prow * rs * ld_bytes + pchunk * 16;
+    const int voff_b = prow * ld_bytes + pchunk * 16;
+    const int pstride_a = 64 * rs * ld_bytes;
+    const int pstride_b = 64 * ld_bytes;
+    auto make_rsrc_a = [&](int64_t gt_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(A.g16 + gt_ * BM * A.row_stride * A.dimp), 0,
+                                                 BM * rs * ld_bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(A.q16 + q_row0 * A.dimp), 0, BN * ld_bytes, 0x00020000);
+
+    // ---- LDS fragment addressing: byte offset for k-slice kk is base ^ (kk << 5) ----------------
+    // (row r, chunk c) lives at r*128 + ((c ^ ((r>>1)&7)) << 4); for this lane r = const + (lane&31)
+    // with const a multiple of 32, c = 2*kk + (lane>>5)  ->  ((lane>>5) ^ sw) << 4 XOR kk << 5.
+    const int sw = ((lane & 31) >> 1) & 7;
+    const int frag_lo = (((lane >> 5) ^ sw) << 4);
+    const int a_base = (wm * WM_ROWS + (lane & 31)) * ROW_BYTES + frag_lo;
+    const int b_base = LDS_B0 + (wn * 64 + (lane & 31)) * ROW_BYTES + frag_lo;
+    int a_addr[4], b_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_addr[kk] = a_base ^ (kk << 5);
+        b_addr[kk] = b_base ^ (kk << 5);
+    }
+
+    // ---- per-lane constants of the epilogue: this lane's two query columns ----------------------
     const int half = lane >> 5;
-    if (L2) {
-#pragma unroll
-        for (int mi = 0; mi < M_REP; ++mi) {
-            float b[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                b[r] = A.gbias[(tile_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * A.row_stride];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int ni = 0; ni < N_REP; ++ni) acc[mi][ni][r] += b[r];
-        }
-    }
+    float tau[N_REP];
+    int64_t qcol[N_REP];
 #pragma unroll
     for (int ni = 0; ni < N_REP; ++ni) {
-        const int64_t qcol = q_row0 + wn * 64 + ni * 32 + (lane & 31);
-        float mx = -INFINITY;
+        qcol[ni] = q_row0 + wn * 64 + ni * 32 + (lane & 31);
+#ifdef MIRX_EXP_NOEPI
+        tau[ni] = INFINITY;
+#else
+        tau[ni] = MODE == 0 ? A.tau[qcol[ni]] : 0.0f;
+#endif
+    }
+    const int region = ph * WARPS_M + wm;                          // private to this wave
+
+    f32x16 acc[M_REP][N_REP];
+
+    // accumulator register r of tile (mi, ni): gallery row (r&3) + 8*(r>>2) + 4*(lane>>5) of the
+    // 32-row tile, query column lane & 31.
+    auto epilogue = [&](int64_t gt_) {
+        const int64_t tile_row0 = gt_ * BM + wm * WM_ROWS;   // in units of sampled rows
+        if (L2) {
+            // bias of the 16 rows of each 32-row tile, 8 loads in flight at a time (more would push
+            // the kernel over 256 VGPRs while the 128 accumulators are live)
 #pragma unroll
-        for (int mi = 0; mi < M_REP; ++mi)
+            for (int mi = 0; mi < M_REP; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
-        if (MODE == 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (half == 0) A.groupmax[qcol * A.ngroups + gt * WARPS_M + wm] = mx;
-        } else {
-            const float tau = A.tau[qcol];
-            if (__any(mx > tau)) {
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float b[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        b[r] = A.gbias[(tile_row0 + mi * 32 + ((r0 + r) & 3) + 8 * ((r0 + r) >> 2) + 4 * half) * A.row_stride];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+#pragma unroll
+                        for (int ni = 0; ni < N_REP; ++ni) acc[mi][ni][r0 + r] += b[r];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < N_REP; ++ni) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
+            if (MODE == 1) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (half == 0) A.groupmax[qcol[ni] * A.ngroups + gt_ * WARPS_M + wm] = mx;
+            } else if (__any(mx > tau[ni])) {
+                // Rare path (about one score per wave tile passes).  No global atomics: the region
+                // (query, this workgroup's phase, this wave row) belongs to this wave alone and its
+                // fill count lives in LDS.  Lanes l and l+32 hold the same query: they take turns.
+                // Rows beyond the region's slots go to the query's shared overflow list.
+                const int cidx = (wn * 64 + ni * 32 + (lane & 31)) * WARPS_M + wm;
+                Cand *dst = A.cand + (qcol[ni] * A.regions + region) * A.slots;
 #pragma unroll
                 for (int mi = 0; mi < M_REP; ++mi)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[mi][ni][r];
                         const int64_t grow = (tile_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * A.row_stride;
-                        if (v > tau && grow < A.n_rows) {
-                            const int p = atomicAdd(&A.cnt[qcol], 1);
-                            if (p < CAND_CAP) {
-                                Cand cd;
-                                cd.s = v;
-                                cd.row = (int32_t)grow;
-                                A.cand[qcol * CAND_CAP + p] = cd;
+                        const bool pass = v > tau[ni] && grow < A.n_rows;
+                        if (__any(pass)) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (pass && half == h) {
+                                    const int c = lcnt[cidx];
+                                    Cand cd;
+                                    cd.s = v;
+                                    cd.row = (int32_t)grow;
+                                    if (c < A.slots) {
+                                        dst[c] = cd;
+                                    } else {
+                                        const int p = atomicAdd(&A.ovf_cnt[qcol[ni]], 1);
+                                        if (p < CAND_OVF) A.ovf[qcol[ni] * CAND_OVF + p] = cd;
+                                    }
+                                    lcnt[cidx] = c + 1;
+                                }
                             }
                         }
                     }
             }
         }
+    };
+
+    bf16x8 fa[M_REP], fb0[N_REP], fb1[N_REP];
+
+#ifdef MIRX_EXP_NOLDS   // diagnostic: fragments are never refreshed (results wrong)
+#define MIRX_LDA(KK, CUR, MI) fa[MI]
+#define MIRX_LDB(KK, CUR, NI) fb0[NI]
+#else
+#define MIRX_LDA(KK, CUR, MI) (*reinterpret_cast<const bf16x8 *>(smem + a_addr[KK] + (CUR) * A_TILE_BYTES + (MI) * 32 * ROW_BYTES))
+#define MIRX_LDB(KK, CUR, NI) (*reinterpret_cast<const bf16x8 *>(smem + b_addr[KK] + (CUR) * B_TILE_BYTES + (NI) * 32 * ROW_BYTES))
+#endif
+#define MIRX_MFMA2(MI, FB_CUR)                                                                    \
+    acc[MI][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MI], FB_CUR[0], acc[MI][0], 0, 0, 0); \
+    acc[MI][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[MI], FB_CUR[1], acc[MI][1], 0, 0, 0);
+    // one k-slice: MFMAs with (fa, FB_CUR); refresh fa[] and fill FB_NXT from buffer NCUR, slice NKK.
+    // sched_group_barrier pins "2 MFMAs, then the reads that refresh what they consumed".
+#define MIRX_SLICE(FB_CUR, FB_NXT, NCUR, NKK)                                     \
+    {                                                                             \
+        MIRX_MFMA2(0, FB_CUR)                                                     \
+        fa[0] = MIRX_LDA(NKK, NCUR, 0);                                           \
+        FB_NXT[0] = MIRX_LDB(NKK, NCUR, 0);                                       \
+        if constexpr (M_REP == 1) FB_NXT[1] = MIRX_LDB(NKK, NCUR, 1);             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
+        if constexpr (M_REP == 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); \
+        else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                   \
+        if constexpr (M_REP > 1) {                                                \
+            MIRX_MFMA2(1, FB_CUR)                                                 \
+            fa[1] = MIRX_LDA(NKK, NCUR, 1);                                       \
+            FB_NXT[1] = MIRX_LDB(NKK, NCUR, 1);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                    \
+        }                                                                         \
+        if constexpr (M_REP > 2) {                                                \
+            MIRX_MFMA2(2, FB_CUR)                                                 \
+            fa[2] = MIRX_LDA(NKK, NCUR, 2);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+            MIRX_MFMA2(3, FB_CUR)                                                 \
+            fa[3] = MIRX_LDA(NKK, NCUR, 3);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+        }                                                                         \
     }
+    // one K-tile held in buffer CUR; KT (runtime) only steers which K-tile the DMA fetches next:
+    // K-tile KT+2 of this gallery tile, or -- in its last two K-tiles -- K-tile 0/1 of the NEXT
+    // gallery tile, so the stream of K-tiles never drains at a tile boundary.  The body is
+    // branch-free around the MFMAs (a branch there makes hipcc copy the 128 accumulator registers
+    // and spill); after the very last K-tile the barrier and the "next" fragment reads still run,
+    // on LDS data nobody consumes.
+#define MIRX_KTILE(CUR, KT)                                                                        \
+    MIRX_SLICE(fb0, fb1, CUR, 1)                                                                   \
+    MIRX_SLICE(fb1, fb0, CUR, 2)                                                                   \
+    MIRX_SLICE(fb0, fb1, CUR, 3)                                                                   \
+    MIRX_KBARRIER(); /* my DMA of the next K-tile landed + every read of buffer CUR has returned */ \
+    if ((KT) + 2 < nk MIRX_EXP_COND) {                                                             \
+        stage_tile<BM>(smem + (CUR) * A_TILE_BYTES, rsrc_a, voff_a, ((KT) + 2) * ROW_BYTES, pstride_a, wave); \
+        stage_tile<BN>(smem + LDS_B0 + (CUR) * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2) * ROW_BYTES, pstride_b, wave); \
+    } else if (have_next MIRX_EXP_COND) {                                                          \
+        stage_tile<BM>(smem + (CUR) * A_TILE_BYTES, rsrc_a_nx, voff_a, ((KT) + 2 - nk) * ROW_BYTES, pstride_a, wave); \
+        stage_tile<BN>(smem + LDS_B0 + (CUR) * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2 - nk) * ROW_BYTES, pstride_b, wave); \
+    }                                                                                              \
+    MIRX_SLICE(fb1, fb0, (CUR) ^ 1, 0)
+
+    int64_t gt = ph;
+    __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc_a(gt);
+
+    stage_tile<BM>(smem, rsrc_a, voff_a, 0, pstride_a, wave);
+    stage_tile<BN>(smem + LDS_B0, rsrc_b, voff_b, 0, pstride_b, wave);
+    __syncthreads();                                   // K-tile 0 visible (and lcnt zeroed)
+    stage_tile<BM>(smem + A_TILE_BYTES, rsrc_a, voff_a, ROW_BYTES, pstride_a, wave);
+    stage_tile<BN>(smem + LDS_B0 + B_TILE_BYTES, rsrc_b, voff_b, ROW_BYTES, pstride_b, wave);
+#pragma unroll
+    for (int mi = 0; mi < M_REP; ++mi)
+        fa[mi] = *reinterpret_cast<const bf16x8 *>(smem + a_addr[0] + mi * 32 * ROW_BYTES);
+    fb0[0] = *reinterpret_cast<const bf16x8 *>(smem + b_addr[0]);
+    fb0[1] = *reinterpret_cast<const bf16x8 *>(smem + b_addr[0] + 32 * ROW_BYTES);
+    fb1[0] = fb0[0];
+    fb1[1] = fb0[1];
+
+    for (;;) {
+        const int64_t gt_nx = gt + plan.nph;
+        const bool have_next = gt_nx < plan.ngt;
+        const __amdgpu_buffer_rsrc_t rsrc_a_nx = make_rsrc_a(have_next ? gt_nx : gt);
+
+#pragma unroll
+        for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < N_REP; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+        for (int kt = 0; kt < nk; kt += 2) {
+            MIRX_KTILE(0, kt)
+            MIRX_KTILE(1, kt + 1)
+        }
+
+        epilogue(gt);
+        if (!have_next) break;
+        gt = gt_nx;
+        rsrc_a = rsrc_a_nx;
+    }
+    if (MODE == 0) {
+        // publish this workgroup's region fill counts (each (query, region) has exactly one writer)
+        __syncthreads();
+        for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) {
+            const int c = lcnt[i];
+            if (c > 0) A.region_cnt[(q_row0 + i / WARPS_M) * A.regions + ph * WARPS_M + (i % WARPS_M)] = c;
+        }
+    }
+#undef MIRX_KTILE
+#undef MIRX_SLICE
+#undef MIRX_MFMA2
+#undef MIRX_LDA
+#undef MIRX_LDB
+}
+
+int device_cus() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu = v > 0 ? v : 256;
+    }
+    return ncu;
 }
 
 template <int BN, int MODE>
-hipError_t launch_bn(const GemmArgs &a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)A_TILE_BYTES + 2 * (size_t)BN * ROW_BYTES;
-    const int64_t rows = a.n_rows;                       // dense rows or sampled rows
-    const int64_t ngt = (rows + BM - 1) / BM;
-    const int64_t nqt = a.nq_pad / BN;
-    const int64_t grid = ngt * nqt;
-    if (grid <= 0) return hipSuccess;
-    if (grid > 0x7FFFFFFF) return hipErrorInvalidValue;
+hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {
+    GemmArgs a = a0;
+    const size_t lds = 2 * (size_t)A_TILE_BYTES + 2 * (size_t)BN * ROW_BYTES +
+                       (MODE == 0 ? (size_t)BN * (8 / (BN / 64)) * sizeof(int) : 0);
+    const Plan plan = make_plan(a.n_rows, a.nq_pad, BN, device_cus() / 8 * 8);
+    if (plan.ngt <= 0 || plan.nqt <= 0) return hipSuccess;
+    a.nph = plan.nph;
+    if (MODE == 0 && (a.regions != plan.nph * (8 / (BN / 64)) || a.slots != region_slots(a.regions)))
+        return hipErrorInvalidValue;
+    // a tile's byte span must fit the 32-bit buffer offsets
+    if ((int64_t)BM * a.row_stride * a.dimp * 2 > 0x7FFFFFFF) return hipErrorInvalidValue;
     hipError_t e;
     if (a.gbias) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<BN, MODE, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_gemm<BN, MODE, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_gemm<BN, MODE, true>), dim3((unsigned)plan.grid), dim3(512), lds, st, a);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<BN, MODE, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_gemm<BN, MODE, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((k_gemm<BN, MODE, false>), dim3((unsigned)plan.grid), dim3(512), lds, st, a);
     }
     return hipGetLastError();
 }
 
 template <int MODE>
 hipError_t launch_mode(const GemmArgs &a, int bn, hipStream_t st) {
-    if (a.dimp % BK || a.nq_pad % bn) return hipErrorInvalidValue;
+    if (a.dimp % (2 * BK) || a.nq_pad % bn) return hipErrorInvalidValue;
     switch (bn) {
         case 64: return launch_bn<64, MODE>(a, st);
         case 128: return launch_bn<128, MODE>(a, st);
@@ -214,6 +426,12 @@ hipError_t launch_mode(const GemmArgs &a, int bn, hipStream_t st) {
 
 int gemm_query_tile(int64_t nq) { return nq <= 64 ? 64 : (nq <= 128 ? 128 : 256); }
 int gemm_groups_per_tile(int bn) { return 8 / (bn / 64); }
+
+void gemm_plan(int64_t n_rows, int64_t nq_pad, int bn, int *regions, int *slots) {
+    const Plan plan = make_plan(n_rows, nq_pad, bn, device_cus() / 8 * 8);
+    *regions = plan.nph * (8 / (bn / 64));
+    *slots = region_slots(*regions);
+}
 
 hipError_t launch_gemm_filter(const GemmArgs &a, int bn, hipStream_t st) { return launch_mode<0>(a, bn, st); }
 hipError_t launch_gemm_groupmax(const GemmArgs &a, int bn, hipStream_t st) { return launch_mode<1>(a, bn, st); }

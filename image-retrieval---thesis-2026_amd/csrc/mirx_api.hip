@@ -74,7 +74,7 @@ struct mirx_index {
     std::vector<Span> spans;              // of the last search
     size_t ev_used = 0;
     // workspace
-    DevBuf q32p, q16, qnorm, tau, cnt, cand, groupmax, fail_list, scores, stage, rankwork;
+    DevBuf q32p, q16, qnorm, tau, cnt, cand, ovf_cnt, ovf, groupmax, fail_list, scores, stage, rankwork;
     int *fail_count = nullptr;            // device
     mirx_search_stats *stats_dev = nullptr;
     int *fail_count_host = nullptr;       // pinned
@@ -262,8 +262,12 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
 
         // ---- tier 1 ---------------------------------------------------------------------
         MIRX_HIP(ix->tau.ensure((size_t)nb_pad * sizeof(float)));
-        MIRX_HIP(ix->cnt.ensure((size_t)nb_pad * sizeof(int)));
-        MIRX_HIP(ix->cand.ensure((size_t)nb_pad * CAND_CAP * sizeof(Cand)));
+        int regions = 0, slots = 0;
+        gemm_plan(ix->size, nb_pad, bn, &regions, &slots);
+        MIRX_HIP(ix->cnt.ensure((size_t)nb_pad * regions * sizeof(int)));
+        MIRX_HIP(ix->cand.ensure((size_t)nb_pad * regions * slots * sizeof(Cand)));
+        MIRX_HIP(ix->ovf_cnt.ensure((size_t)nb_pad * sizeof(int)));
+        MIRX_HIP(ix->ovf.ensure((size_t)nb_pad * CAND_OVF * sizeof(Cand)));
         MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
         GemmArgs ga{};
         ga.g16 = ix->g16;
@@ -272,8 +276,12 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         ga.nq_pad = nb_pad;
         ga.dimp = ix->dimp;
         ga.tau = ix->tau.as<float>();
-        ga.cnt = ix->cnt.as<int>();
+        ga.regions = regions;
+        ga.slots = slots;
+        ga.region_cnt = ix->cnt.as<int>();
         ga.cand = ix->cand.as<Cand>();
+        ga.ovf_cnt = ix->ovf_cnt.as<int>();
+        ga.ovf = ix->ovf.as<Cand>();
         if (ix->force_tau_bits != 0x7fc00000u) {
             // test hook: one fixed threshold for every query
             std::vector<float> t((size_t)nb_pad, INFINITY);
@@ -300,7 +308,8 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
             MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, ix->sample_rank,
                                        ix->tau.as<float>(), st));
         }
-        MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
+        MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * regions * sizeof(int), st));
+        MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
         MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, sizeof(int), st));
         ga.n_rows = ix->size;
         ga.row_stride = 1;
@@ -316,8 +325,12 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         fa.ids = ix->ids;
         fa.gnorm_max_bits = ix->gnorm_max_bits;
         fa.tau = ix->tau.as<float>();
-        fa.cnt = ix->cnt.as<int>();
+        fa.regions = regions;
+        fa.slots = slots;
+        fa.region_cnt = ix->cnt.as<int>();
         fa.cand = ix->cand.as<Cand>();
+        fa.ovf_cnt = ix->ovf_cnt.as<int>();
+        fa.ovf = ix->ovf.as<Cand>();
         fa.exclude = exb;
         fa.n_rows = ix->size;
         fa.dimp = ix->dimp;
@@ -397,7 +410,7 @@ void mirx_index_destroy(mirx_index *ix) {
     if (ix->stats_dev) (void)hipFree(ix->stats_dev);
     if (ix->fail_count_host) (void)hipHostFree(ix->fail_count_host);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->groupmax,
+    for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->ovf_cnt, &ix->ovf, &ix->groupmax,
                       &ix->fail_list, &ix->scores, &ix->stage, &ix->rankwork})
         b->release();
     delete ix;

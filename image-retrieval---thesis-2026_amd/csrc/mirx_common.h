@@ -26,9 +26,10 @@ int fail(int code, const std::string &msg);
 
 // ---- sizes ----------------------------------------------------------------------------
 constexpr int WAVE = 64;
-constexpr int DIM_ALIGN = 64;        // rows are stored padded to a multiple of 64 elements
+constexpr int DIM_ALIGN = 128;       // rows are stored padded to a multiple of 128 elements (2 GEMM K-steps)
 constexpr int ROW_ALIGN = 256;       // gallery capacity is a multiple of the GEMM M tile
 constexpr int CAND_CAP = 1024;       // per-query candidate capacity of the threshold filter
+constexpr int CAND_OVF = 256;        // per-query shared overflow list (global atomics, rare)
 constexpr int MAX_K = 1024;
 constexpr int MAX_DIMP = 4096;
 

@@ -54,15 +54,22 @@ struct GemmArgs {
     int64_t row_stride;    // gallery row step between consecutive tile rows (1 = dense)
     int64_t nq_pad;        // multiple of the query tile
     int dimp;
-    // filter mode
+    // filter mode: every (query, producer wave) owns a private region of CAND_SLOTS entries, so
+    // the epilogue appends with plain stores; rows beyond a region go to a shared overflow list
     const float *tau;      // [nq_pad]
-    int *cnt;              // [nq_pad]
-    Cand *cand;            // [nq_pad, CAND_CAP]
+    int regions, slots;    // producer regions per query and slots per region (from gemm_plan)
+    int nph;               // phases per query tile (filled by the launcher)
+    int *region_cnt;       // [nq_pad, regions]  rows that passed, per region (zeroed per search)
+    Cand *cand;            // [nq_pad, regions, slots]
+    int *ovf_cnt;          // [nq_pad]           (zeroed per search)
+    Cand *ovf;             // [nq_pad, CAND_OVF]
     // group-max mode
     float *groupmax;       // [nq_pad, ngroups]
     int ngroups;
 };
 int gemm_query_tile(int64_t nq);                 // query-tile width chosen for nq (64/128/256)
+// Producer regions per query and slots per region of the filter GEMM for this problem.
+void gemm_plan(int64_t n_rows, int64_t nq_pad, int bn, int *regions, int *slots);
 int gemm_groups_per_tile(int bn);                // group-max groups per 256-row gallery tile
 hipError_t launch_gemm_filter(const GemmArgs &a, int bn, hipStream_t st);
 hipError_t launch_gemm_groupmax(const GemmArgs &a, int bn, hipStream_t st);
@@ -75,8 +82,11 @@ struct FinalizeArgs {
     const int64_t *ids;      // [rows]
     const unsigned *gnorm_max_bits;
     const float *tau;
-    const int *cnt;
-    const Cand *cand;
+    int regions, slots;
+    const int *region_cnt;   // [nq, regions]
+    const Cand *cand;        // [nq, regions, slots]
+    const int *ovf_cnt;      // [nq]
+    const Cand *ovf;         // [nq, CAND_OVF]
     const int64_t *exclude;  // or null
     int64_t n_rows;
     int dimp, k, metric, nq;

@@ -31,6 +31,8 @@ def main():
         ix.add(torch.nn.functional.normalize(torch.randn(m, a.d, generator=g, device=dev), dim=1))
     q = torch.nn.functional.normalize(
         torch.randn(a.q, a.d, generator=torch.Generator(device=dev).manual_seed(4321), device=dev), dim=1)
+    from mirx import _lib
+    ix.set_option(_lib.OPT_PROFILE, 1)
     ix.search(q, a.k)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -39,9 +41,11 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     st = ix.last_stats()
+    tm = ix.last_timings()
     flops = 2.0 * a.q * a.n * a.d
     print(f"N={a.n} D={a.d} Q={a.q} k={a.k} {a.metric}: {dt*1e3:.2f} ms/search, {a.q/dt:.0f} q/s, "
-          f"{flops/dt/1e12:.1f} TFLOP/s end-to-end of the search call; stats={st}")
+          f"{flops/dt/1e12:.1f} TFLOP/s end-to-end of the search call; gemm {tm['gemm']:.2f} ms = "
+          f"{flops/tm['gemm']/1e9:.0f} TFLOP/s; stages={ {k: round(v, 3) for k, v in tm.items()} } stats={st}")
 
 
 if __name__ == "__main__":
