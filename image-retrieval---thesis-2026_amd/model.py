@@ -90,18 +90,23 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
 
 def _dense_block_fused(block, x, cache):
     """Inference path of one dense block (CUDA, eval):
-       per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2 folded into its
-       weights/bias) -> relu2 in place -> conv2 (3x3) -> 32 new channels copied into the buffer."""
+       per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
+       its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
+       into the block buffer."""
     lib = _lib.load()
     b, _, h, w = x.shape
     buf = torch.empty((b, block.cout, h, w), dtype=torch.float32, device=x.device)
     buf[:, : block.cin] = x
     c = block.cin
     for name, layer in block.items():
-        sc1, sh1, w1, b1 = cache[name]
+        sc1, sh1, w1, b1, ones = cache[name]
         y = _fused_bn_relu(lib, buf, c, sc1, sh1)
-        y = F.conv2d(y, w1, b1)
-        y = F.conv2d(F.relu_(y), layer.conv2.weight, None, padding=1)
+        y = F.conv2d(y, w1)                       # norm2's scale is folded into w1 ...
+        # ... and its shift + relu2 run as ONE in-place HIP pass (a conv bias would cost a separate
+        # add kernel plus a clamp kernel under PyTorch-ROCm)
+        _lib.check(lib.mirx_bn_relu_nchw(_ptr(y), y.shape[1] * h * w, _ptr(ones), _ptr(b1), b, y.shape[1], h * w,
+                                         _ptr(y), _stream(y.device)), "mirx_bn_relu_nchw")
+        y = F.conv2d(y, layer.conv2.weight, None, padding=1)
         buf[:, c: c + GROWTH] = y
         c += GROWTH
     return buf
@@ -226,7 +231,7 @@ class DenseNet121(nn.Module):
                     sc1, sh1 = _bn_affine(layer.norm1)
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
-                    blk[lname] = (sc1, sh1, w1, sh2)
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2))
                 cache[name] = blk
             elif name.startswith("transition"):
                 cache[name] = _bn_affine(m.norm)
