@@ -84,6 +84,113 @@ __global__ __launch_bounds__(256) void k_scores_f64(const float *__restrict__ q3
     }
 }
 
+// ---- fp64 score tile, LDS-resident queries --------------------------------------------------
+// The exact tier's work horse for more than a handful of queries.  QT (<= 16) queries sit in LDS
+// as doubles, so one pass over a gallery row serves 16 queries (HBM traffic / 4 vs the register
+// kernel).  Rows are taken four at a time and reduced "transposed": after the off=32 and off=16
+// levels of the lane tree each quarter of the wave carries ONE row, so the four lower levels run
+// once for four rows -- the association of every sum is exactly the lane tree of search_ref.c.
+// grid.x = query groups (fast index: consecutive workgroups share gallery rows in L2),
+// grid.y = blocks of SCORE_ROWS gallery rows.
+constexpr int SCORE_ROWS = 1024;                 // gallery rows per workgroup (128 per wave, 8 waves)
+
+template <int METRIC, int CPL>
+__global__ __launch_bounds__(512, 2) void k_scores_f64_lds(const float *__restrict__ q32p,
+                                                        const int32_t *__restrict__ qlist, int nq, int qt,
+                                                        const float *__restrict__ g32, int64_t n, int dimp,
+                                                        double *__restrict__ out, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *qs = reinterpret_cast<double *>(smem);                 // [qt][dimp]
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int nchunk = dimp >> 2;
+    const int qbase = blockIdx.x * qt;
+    const int nloc = (nq - qbase) < qt ? (nq - qbase) : qt;
+    for (int i = threadIdx.x; i < qt * dimp; i += 512) {
+        const int t = i / dimp, e = i - t * dimp;
+        double v = 0.0;
+        if (t < nloc) {
+            const int64_t qi = qlist ? (int64_t)qlist[qbase + t] : (int64_t)(qbase + t);
+            v = (double)q32p[qi * dimp + e];
+        }
+        qs[i] = v;
+    }
+    __syncthreads();
+    const int64_t wave_row0 = (int64_t)blockIdx.y * SCORE_ROWS + wave * (SCORE_ROWS / 8);
+    const int sel_hi = lane >> 5, sel_16 = (lane >> 4) & 1;
+    const int my_row_in4 = sel_hi + 2 * sel_16;                     // row of the 4-group this lane ends up holding
+    for (int blk = 0; blk < SCORE_ROWS / 8 / 64; ++blk) {           // 64 rows per output block
+        const int64_t r0 = wave_row0 + blk * 64;
+        if (r0 >= n) break;
+        double keep[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) keep[t] = 0.0;
+        for (int grp = 0; grp < 16; ++grp) {                        // 4 rows per group
+            const int64_t rg = r0 + grp * 4;
+            if (rg >= n) break;
+            float4 gv[4][CPL];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = rg + r < n ? rg + r : n - 1;    // clamp: results of rows >= n are not stored
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int chunk = lane + WAVE * c;
+                    gv[r][c] = chunk < nchunk ? *reinterpret_cast<const float4 *>(g32 + row * dimp + 4 * chunk)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                if (t >= nloc) break;
+                double p[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int chunk = lane + WAVE * c;
+                    double qv[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (chunk < nchunk) {
+                        const double2 a = *reinterpret_cast<const double2 *>(qs + (int64_t)t * dimp + 4 * chunk);
+                        const double2 b = *reinterpret_cast<const double2 *>(qs + (int64_t)t * dimp + 4 * chunk + 2);
+                        qv[0] = a.x; qv[1] = a.y; qv[2] = b.x; qv[3] = b.y;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double gd[4] = {(double)gv[r][c].x, (double)gv[r][c].y, (double)gv[r][c].z,
+                                              (double)gv[r][c].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (METRIC == 0) {
+                                p[r] = fma(qv[e], gd[e], p[r]);
+                            } else {
+                                const double d = qv[e] - gd[e];
+                                p[r] = fma(d, d, p[r]);
+                            }
+                        }
+                    }
+                }
+                // level off=32: lanes < 32 keep rows 0 and 2, lanes >= 32 rows 1 and 3
+                const double k01 = sel_hi ? p[1] : p[0], s01 = sel_hi ? p[0] : p[1];
+                const double k23 = sel_hi ? p[3] : p[2], s23 = sel_hi ? p[2] : p[3];
+                const double a01 = k01 + __shfl_xor(s01, 32, 64);
+                const double a23 = k23 + __shfl_xor(s23, 32, 64);
+                // level off=16: lanes with bit 4 clear keep the (0,1) track, the others the (2,3) track
+                const double kk = sel_16 ? a23 : a01, ss = sel_16 ? a01 : a23;
+                double v = kk + __shfl_xor(ss, 16, 64);
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+                if (METRIC == 1) v = -v;
+                // lane (16*q + grp) of quarter q keeps row 4*grp + row(q) of the 64-row block
+                if ((lane & 15) == grp) keep[t] = v;
+            }
+        }
+        // lane l holds row r0 + 4*(l & 15) + my_row_in4 for every query
+        const int64_t orow = r0 + 4 * (lane & 15) + my_row_in4;
+        if (orow < n) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < nloc) out[(int64_t)(qbase + t) * ld + orow] = keep[t];
+        }
+    }
+}
+
 // Fallback for very wide rows (dimp > 2048): one query per workgroup row, q from memory.
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_scores_f64_wide(const float *__restrict__ q32p,
@@ -297,6 +404,27 @@ template <int METRIC>
 hipError_t launch_scores_t(const float *q32p, const int32_t *qlist, int nq, const float *g32, int64_t n,
                            int dimp, double *out, int64_t ld, hipStream_t st) {
     const unsigned gx = (unsigned)((n + 255) / 256);
+    if (nq >= 8 && dimp <= 2048) {
+        // LDS-resident queries: as many as fit 128 KiB of doubles, at most 16
+        int qt = (128 * 1024) / (dimp * 8);
+        qt = qt > 16 ? 16 : qt;
+        const size_t lds = (size_t)qt * dimp * sizeof(double);
+        const dim3 grid((unsigned)((nq + qt - 1) / qt), (unsigned)((n + SCORE_ROWS - 1) / SCORE_ROWS));
+#define MIRX_LDS_LAUNCH(CPL)                                                                              \
+    {                                                                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_scores_f64_lds<METRIC, CPL>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (e != hipSuccess) return e;                                                                    \
+        hipLaunchKernelGGL((k_scores_f64_lds<METRIC, CPL>), grid, dim3(512), lds, st, q32p, qlist, nq, qt, g32, n, \
+                           dimp, out, ld);                                                                \
+    }
+        if (dimp <= 256) MIRX_LDS_LAUNCH(1)
+        else if (dimp <= 512) MIRX_LDS_LAUNCH(2)
+        else if (dimp <= 1024) MIRX_LDS_LAUNCH(4)
+        else MIRX_LDS_LAUNCH(8)
+#undef MIRX_LDS_LAUNCH
+        return hipGetLastError();
+    }
     if (dimp <= 256) {
         hipLaunchKernelGGL((k_scores_f64<METRIC, 1, 4>), dim3(gx, (nq + 3) / 4), dim3(256), 0, st, q32p,
                            qlist, nq, g32, n, dimp, out, ld);
