@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_f64_lds(const float *__restri
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                if (t >= nloc) break;
+                if (t >= nloc) continue;
                 double p[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {

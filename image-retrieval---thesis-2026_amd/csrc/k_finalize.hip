@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
     __shared__ Hit hits[CAND_CAP];
     __shared__ int sh_ok, sh_m;
     __shared__ float sh_lo;
-    const int qi = blockIdx.x;
+    const int slot_q = blockIdx.x;                                  // index into tau / candidate buffers
+    const int qi = A.qmap ? A.qmap[slot_q] : slot_q;                // original query number
     const int wave = threadIdx.x >> 6, lane = lane_id();
     // gather the producer regions (+ the shared overflow list) of this query into `keys`
     __shared__ int sh_cnt, sh_raw, sh_ovf;
@@ -86,19 +87,19 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
             keys[p] = ((unsigned long long)f32_orderable(cd.s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)cd.row);
     };
     for (int rg = threadIdx.x; rg < A.regions; rg += 256) {
-        const int cr = A.region_cnt[(int64_t)qi * A.regions + rg];
+        const int cr = A.region_cnt[(int64_t)slot_q * A.regions + rg];
         if (cr > 0) {
             atomicAdd(&sh_raw, cr);
             const int take = cr < A.slots ? cr : A.slots;
-            const Cand *src = A.cand + ((int64_t)qi * A.regions + rg) * A.slots;
+            const Cand *src = A.cand + ((int64_t)slot_q * A.regions + rg) * A.slots;
             for (int i = 0; i < take; ++i) push(src[i]);
         }
     }
     {
-        const int oc = A.ovf_cnt[qi];
+        const int oc = A.ovf_cnt[slot_q];
         if (oc > CAND_OVF && threadIdx.x == 0) sh_ovf = 1;         // overflow list itself overflowed
         const int take = oc < CAND_OVF ? oc : CAND_OVF;
-        for (int i = threadIdx.x; i < take; i += 256) push(A.ovf[(int64_t)qi * CAND_OVF + i]);
+        for (int i = threadIdx.x; i < take; i += 256) push(A.ovf[(int64_t)slot_q * CAND_OVF + i]);
     }
     __syncthreads();
     const int c_raw = sh_raw;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
     const int m2 = pow2_ceil(c > 1 ? c : 1);
     bitonic_lds(keys, m2, [](unsigned long long x, unsigned long long y) { return x > y; });
     if (threadIdx.x == 0) {
-        int ok = (!overflow && c >= k_eff) ? 1 : 0;
+        int ok = (!overflow && c >= k_eff) ? 1 : 0, retry = 0;
         float lo = 0.0f;
         if (ok) {
             const float kth = f32_from_orderable((uint32_t)(keys[k_eff - 1] >> 32));
@@ -122,13 +123,23 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
             if (METRIC == 1) eps += 1.1920929e-7f * (gmax * gmax + qn * gmax) * 1.00001f;
             lo = kth - 2.0f * eps;
             lo -= fabsf(lo) * 2.4e-7f + 1e-37f;            // round toward -inf with margin
-            ok = (A.tau[qi] < lo) ? 1 : 0;
-            if (!ok) atomicAdd((unsigned long long *)&A.stats->incomplete, 1ull);
+            ok = (A.tau[slot_q] < lo) ? 1 : 0;
+            if (!ok) {
+                atomicAdd((unsigned long long *)&A.stats->incomplete, 1ull);
+                if (A.retry_list) {
+                    // the k-th best s~ is final (every row above tau was seen), so tau2 just below
+                    // `lo` makes the next filter pass complete by construction
+                    const int p = atomicAdd(A.fail_count + 1, 1);
+                    A.retry_list[p] = qi;
+                    A.tau2[qi] = lo - (fabsf(lo) * 2.4e-7f + 1e-37f);
+                    retry = 1;
+                }
+            }
         } else {
             if (overflow) atomicAdd((unsigned long long *)&A.stats->overflowed, 1ull);
             else atomicAdd((unsigned long long *)&A.stats->incomplete, 1ull);
         }
-        if (!ok) {
+        if (!ok && !retry) {
             const int p = atomicAdd(A.fail_count, 1);
             A.fail_list[p] = qi;
         }
@@ -184,7 +195,33 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_gather_queries(const uint16_t *__restrict__ q16,
+                                                        const float *__restrict__ tau2,
+                                                        const int32_t *__restrict__ list, int n, int dimp,
+                                                        uint16_t *__restrict__ q16r, float *__restrict__ taur) {
+    const int64_t i = blockIdx.x;
+    const int chunks = dimp / 8;                                    // 16-byte pieces per row
+    uint4 *dst = reinterpret_cast<uint4 *>(q16r + i * dimp);
+    if (i < n) {
+        const int32_t qi = list[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(q16 + (int64_t)qi * dimp);
+        for (int c = threadIdx.x; c < chunks; c += 256) dst[c] = src[c];
+        if (threadIdx.x == 0) taur[i] = tau2[qi];
+    } else {
+        for (int c = threadIdx.x; c < chunks; c += 256) dst[c] = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x == 0) taur[i] = INFINITY;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_gather_queries(const uint16_t *q16, const float *tau2, const int32_t *list, int n,
+                                 int64_t n_pad, int dimp, uint16_t *q16r, float *taur, hipStream_t st) {
+    if (n_pad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_queries, dim3((unsigned)n_pad), dim3(256), 0, st, q16, tau2, list, n, dimp, q16r,
+                       taur);
+    return hipGetLastError();
+}
 
 hipError_t launch_select_tau(const float *groupmax, int ngroups, int64_t nq, int64_t nq_pad, int rank_j,
                              float *tau, hipStream_t st) {

@@ -74,7 +74,8 @@ struct mirx_index {
     std::vector<Span> spans;              // of the last search
     size_t ev_used = 0;
     // workspace
-    DevBuf q32p, q16, qnorm, tau, cnt, cand, ovf_cnt, ovf, groupmax, fail_list, scores, stage, rankwork;
+    DevBuf q32p, q16, qnorm, tau, cnt, cand, ovf_cnt, ovf, groupmax, fail_list, retry_list, tau2, q16r, taur,
+        scores, stage, rankwork;
     int *fail_count = nullptr;            // device
     mirx_search_stats *stats_dev = nullptr;
     int *fail_count_host = nullptr;       // pinned
@@ -269,6 +270,8 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         MIRX_HIP(ix->ovf_cnt.ensure((size_t)nb_pad * sizeof(int)));
         MIRX_HIP(ix->ovf.ensure((size_t)nb_pad * CAND_OVF * sizeof(Cand)));
         MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
+        MIRX_HIP(ix->retry_list.ensure((size_t)nb_pad * sizeof(int32_t)));
+        MIRX_HIP(ix->tau2.ensure((size_t)nb_pad * sizeof(float)));
         GemmArgs ga{};
         ga.g16 = ix->g16;
         ga.q16 = ix->q16.as<uint16_t>();
@@ -310,7 +313,7 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         }
         MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * regions * sizeof(int), st));
         MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
-        MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, sizeof(int), st));
+        MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, 2 * sizeof(int), st));
         ga.n_rows = ix->size;
         ga.row_stride = 1;
         {
@@ -342,14 +345,62 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
         fa.out_val = ovb;
         fa.fail_list = ix->fail_list.as<int32_t>();
         fa.fail_count = ix->fail_count;
+        fa.retry_list = ix->retry_list.as<int32_t>();
+        fa.tau2 = ix->tau2.as<float>();
+        fa.qmap = nullptr;
         fa.stats = ix->stats_dev;
         {
             StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
             MIRX_HIP(launch_finalize(fa, st));
         }
-        MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         MIRX_HIP(hipStreamSynchronize(st));
-        const int nfail = *ix->fail_count_host;
+        const int nretry = ix->fail_count_host[1];
+        if (nretry > 0) {
+            // second chance: same filter GEMM over the gathered queries with tau2 = kth(s~) - 2*eps
+            const int bn2 = gemm_query_tile(nretry);
+            const int64_t nr_pad = round_up(nretry, bn2);
+            int regions2 = 0, slots2 = 0;
+            gemm_plan(ix->size, nr_pad, bn2, &regions2, &slots2);
+            MIRX_HIP(ix->q16r.ensure((size_t)nr_pad * ix->dimp * sizeof(uint16_t)));
+            MIRX_HIP(ix->taur.ensure((size_t)nr_pad * sizeof(float)));
+            MIRX_HIP(ix->cnt.ensure((size_t)nr_pad * regions2 * sizeof(int)));
+            MIRX_HIP(ix->cand.ensure((size_t)nr_pad * regions2 * slots2 * sizeof(Cand)));
+            MIRX_HIP(launch_gather_queries(ix->q16.as<uint16_t>(), ix->tau2.as<float>(), ix->retry_list.as<int32_t>(),
+                                           nretry, nr_pad, ix->dimp, ix->q16r.as<uint16_t>(), ix->taur.as<float>(),
+                                           st));
+            MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nr_pad * regions2 * sizeof(int), st));
+            MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nr_pad * sizeof(int), st));
+            GemmArgs g2 = ga;
+            g2.q16 = ix->q16r.as<uint16_t>();
+            g2.nq_pad = nr_pad;
+            g2.tau = ix->taur.as<float>();
+            g2.regions = regions2;
+            g2.slots = slots2;
+            g2.region_cnt = ix->cnt.as<int>();
+            g2.cand = ix->cand.as<Cand>();
+            {
+                StageTimer t(ix, st, MIRX_STAGE_GEMM);
+                MIRX_HIP(launch_gemm_filter(g2, bn2, st));
+            }
+            FinalizeArgs f2 = fa;
+            f2.tau = ix->taur.as<float>();
+            f2.regions = regions2;
+            f2.slots = slots2;
+            f2.region_cnt = ix->cnt.as<int>();
+            f2.cand = ix->cand.as<Cand>();
+            f2.nq = nretry;
+            f2.retry_list = nullptr;          // no third chance: what fails now goes to the exact scan
+            f2.tau2 = nullptr;
+            f2.qmap = ix->retry_list.as<int32_t>();
+            {
+                StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
+                MIRX_HIP(launch_finalize(f2, st));
+            }
+            MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            MIRX_HIP(hipStreamSynchronize(st));
+        }
+        const int nfail = ix->fail_count_host[0];
         if (nfail > 0) {
             StageTimer t(ix, st, MIRX_STAGE_EXACT);
             int rc = exact_pass(ix, ix->q32p.as<float>(), ix->fail_list.as<int32_t>(), nfail, k, exb, ofb,
@@ -387,10 +438,10 @@ int mirx_index_create(int dim, int metric, int device, mirx_index **out) {
     hipError_t e;
     if ((e = hipMalloc(&ix->gnorm_max_bits, sizeof(unsigned))) != hipSuccess ||
         (e = hipMemset(ix->gnorm_max_bits, 0, sizeof(unsigned))) != hipSuccess ||
-        (e = hipMalloc(&ix->fail_count, sizeof(int))) != hipSuccess ||
+        (e = hipMalloc(&ix->fail_count, 2 * sizeof(int))) != hipSuccess ||
         (e = hipMalloc(&ix->stats_dev, sizeof(mirx_search_stats))) != hipSuccess ||
         (e = hipMemset(ix->stats_dev, 0, sizeof(mirx_search_stats))) != hipSuccess ||
-        (e = hipHostMalloc(&ix->fail_count_host, sizeof(int))) != hipSuccess) {
+        (e = hipHostMalloc(&ix->fail_count_host, 2 * sizeof(int))) != hipSuccess) {
         mirx_index_destroy(ix);
         return fail(MIRX_ENOMEM, std::string("index_create: ") + hipGetErrorString(e));
     }
@@ -411,7 +462,8 @@ void mirx_index_destroy(mirx_index *ix) {
     if (ix->fail_count_host) (void)hipHostFree(ix->fail_count_host);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->ovf_cnt, &ix->ovf, &ix->groupmax,
-                      &ix->fail_list, &ix->scores, &ix->stage, &ix->rankwork})
+                      &ix->fail_list, &ix->retry_list, &ix->tau2, &ix->q16r, &ix->taur, &ix->scores, &ix->stage,
+                      &ix->rankwork})
         b->release();
     delete ix;
 }

@@ -93,10 +93,19 @@ struct FinalizeArgs {
     double *out_f64;         // [nq, k]
     int64_t *out_ids;        // [nq, k]
     float *out_val;          // [nq, k]
-    int32_t *fail_list;      // [nq]
-    int *fail_count;         // [1]
+    int32_t *fail_list;      // [nq]   queries for the exact scan (original query numbers)
+    int *fail_count;         // [2]    [0] exact list length, [1] retry list length
+    // second chance (pass 1 only; null in the retry pass): a query whose guard failed only because
+    // tau was too high is re-filtered with tau2 = kth(s~) - 2*eps, which is complete by construction
+    int32_t *retry_list;     // [nq]
+    float *tau2;             // [nq]
+    // retry pass: slot i of the candidate buffers / tau belongs to original query qmap[i]
+    const int32_t *qmap;     // or null (identity)
     mirx_search_stats *stats;  // device copy
 };
+// q16r[i] = q16[list[i]] for i < n, zero rows and tau = +inf up to n_pad (retry pass input).
+hipError_t launch_gather_queries(const uint16_t *q16, const float *tau2, const int32_t *list, int n,
+                                 int64_t n_pad, int dimp, uint16_t *q16r, float *taur, hipStream_t st);
 hipError_t launch_select_tau(const float *groupmax, int ngroups, int64_t nq, int64_t nq_pad,
                              int rank_j, float *tau, hipStream_t st);
 hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t st);

@@ -174,3 +174,22 @@ def test_l2_normalize_kernel():
     z = torch.randn(10, 37)
     np.testing.assert_allclose(l2_normalize_(z.clone().cuda()).cpu().numpy(),
                                torch.nn.functional.normalize(z, dim=1).numpy(), atol=2e-7)
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_clustered_gallery_second_chance_pass(metric):
+    """Tight clusters make the sampled threshold too high for the guard; the second filter pass
+    (tau2 = kth - 2 eps) must answer those queries in the MFMA tier -- and identically to the oracle."""
+    from mirx.index import FlatIndex, metric_code
+    n, d, nq, ncls = 60000, 256, 96, 40
+    g = torch.Generator().manual_seed(3)
+    centers = torch.nn.functional.normalize(torch.randn(ncls, d, generator=g), dim=1)
+    lab = torch.randint(0, ncls, (n,), generator=g)
+    x = torch.nn.functional.normalize(centers[lab] + 0.3 / d ** 0.5 * torch.randn(n, d, generator=g), dim=1)
+    q = torch.nn.functional.normalize(x[torch.randint(0, n, (nq,), generator=g)] + 0.01 * torch.randn(nq, d, generator=g), dim=1)
+    ix = FlatIndex(d, metric, 0)
+    ix.add(x)
+    _check(ix, q, 10, metric_code(metric), gallery=x)
+    st = ix.last_stats()
+    assert st["incomplete"] > 0, st                       # the first pass did reject queries ...
+    assert st["tier1_answered"] >= nq * 0.9, st           # ... and the second pass answered them
