@@ -670,4 +670,11 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
     return MIRX_OK;
 }
 
+int mirx_dwconv7x7_nchw_to_nhwc(const float *x, const float *w, const float *bias, int64_t n, int c, int h,
+                                int wd, float *y, void *stream) {
+    MIRX_CHECK(x && w && y && n >= 0 && c >= 1 && h >= 1 && wd >= 1, "dwconv7x7: bad argument");
+    MIRX_HIP(launch_dwconv7(x, w, bias, n, c, h, wd, y, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 }  // extern "C"

@@ -26,6 +26,10 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 
+// ---- k_convnext.hip ---------------------------------------------------------------------
+hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
+                          float *y, hipStream_t st);
+
 // ---- k_exact.hip ------------------------------------------------------------------------
 // out[i*ld + j] = fp64 ranking score of query qlist[i] (or i when qlist == null) vs row j.
 hipError_t launch_scores_f64(const float *q32p, const int32_t *qlist, int nq, const float *g32,

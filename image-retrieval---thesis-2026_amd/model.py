@@ -293,8 +293,152 @@ class DenseNet121(nn.Module):
         return F.normalize(x, dim=1)
 
 
+# =================================================================================================
+# ConvNeXtV2-base (reference model.py:87-117 around timm 'convnextv2_base.fcmae_ft_in22k_in1k_384',
+# num_classes=0).  timm is not a dependency: the module tree below reproduces its parameter names
+# (stem.0/1, stages.N.downsample.0/1, stages.N.blocks.M.{conv_dw,norm,mlp.fc1,mlp.grn,mlp.fc2},
+# head.norm) so reference checkpoints (`convnext.*`, `fc.*`) load unchanged.
+# =================================================================================================
+CNX_DEPTHS = (3, 3, 27, 3)
+CNX_DIMS = (128, 256, 512, 1024)
+CNX_EPS = 1e-6
+
+
+class _LayerNorm2d(nn.LayerNorm):
+    """LayerNorm over the channel axis of an NCHW tensor (timm LayerNorm2d)."""
+
+    def forward(self, x):
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias,
+                            self.eps).permute(0, 3, 1, 2)
+
+
+class _GRN(nn.Module):
+    """Global response normalisation on NHWC (timm GlobalResponseNorm, channels_last)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        g = torch.linalg.vector_norm(x, ord=2, dim=(1, 2), keepdim=True)
+        n = g / (g.mean(dim=-1, keepdim=True) + 1e-6)
+        return x + torch.addcmul(self.bias, self.weight, x * n)
+
+
+class _CnxMlp(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.grn = _GRN(4 * dim)
+        self.fc2 = nn.Linear(4 * dim, dim)
+
+    def forward(self, x):
+        return self.fc2(self.grn(self.act(self.fc1(x))))
+
+
+class _CnxBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=CNX_EPS)
+        self.mlp = _CnxMlp(dim)
+
+    def forward(self, x):
+        if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32:
+            # MI355X path: depthwise 7x7 + the NCHW->NHWC permute in one HIP pass
+            lib = _lib.load()
+            xc = x.contiguous()
+            b, c, h, w = xc.shape
+            y = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.mirx_dwconv7x7_nchw_to_nhwc(_ptr(xc), _ptr(self.conv_dw.weight.detach().contiguous()),
+                                                           _ptr(self.conv_dw.bias.detach().contiguous()), b, c, h, w,
+                                                           _ptr(y), _stream(x.device)), "mirx_dwconv7x7")
+        else:
+            y = self.conv_dw(x).permute(0, 2, 3, 1)
+        y = self.mlp(self.norm(y))
+        return y.permute(0, 3, 1, 2) + x
+
+
+class _CnxStage(nn.Module):
+    def __init__(self, cin, cout, depth, downsample):
+        super().__init__()
+        if downsample:
+            self.downsample = nn.Sequential(_LayerNorm2d(cin, eps=CNX_EPS), nn.Conv2d(cin, cout, kernel_size=2, stride=2))
+        else:
+            self.downsample = nn.Identity()
+        self.blocks = nn.Sequential(*[_CnxBlock(cout) for _ in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+class _CnxHead(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = _LayerNorm2d(dim, eps=CNX_EPS)
+
+    def forward(self, x):
+        return torch.flatten(self.norm(x.mean(dim=(2, 3), keepdim=True)), 1)
+
+
+class _ConvNeXtV2Backbone(nn.Module):
+    """timm-shaped backbone (num_classes=0): forward(x) -> pooled, head-normalised features."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_features = CNX_DIMS[-1]
+        self.stem = nn.Sequential(nn.Conv2d(3, CNX_DIMS[0], kernel_size=4, stride=4), _LayerNorm2d(CNX_DIMS[0], eps=CNX_EPS))
+        stages, cin = [], CNX_DIMS[0]
+        for i, (d, c) in enumerate(zip(CNX_DEPTHS, CNX_DIMS)):
+            stages.append(_CnxStage(cin, c, d, downsample=i > 0))
+            cin = c
+        self.stages = nn.Sequential(*stages)
+        self.head = _CnxHead(cin)
+        for m in self.modules():           # timm's init: trunc_normal(std=.02) weights, zero biases
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        return self.head(self.stages(self.stem(x)))
+
+
+class ConvNeXtV2(nn.Module):
+    """Reference model.py:87-117: `convnext` backbone, optional `fc`, unit-norm output."""
+
+    def __init__(self, pretrained=False, embedding_dim=None, weights=None):
+        super().__init__()
+        if pretrained and weights is None:
+            raise RuntimeError("pretrained=True needs a download in the reference (model.py:96-100); "
+                               "pass weights=<state dict or path> instead")
+        self.convnext = _ConvNeXtV2Backbone()
+        in_features = self.convnext.num_features
+        self.fc = nn.Linear(in_features, embedding_dim) if embedding_dim else None
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            for key in ("state-dict", "state_dict"):
+                if isinstance(sd, dict) and key in sd:
+                    sd = sd[key]
+            self.load_state_dict(sd, strict=False)
+
+    def forward(self, x):
+        x = self.convnext(x)
+        x = torch.flatten(x, 1)
+        if self.fc:
+            x = self.fc(x)
+        if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 and x.is_contiguous():
+            from .index import l2_normalize_
+            return l2_normalize_(x)                # HIP F.normalize (model.py:116)
+        return F.normalize(x, dim=1)
+
+
 def build_model(model_type, embedding_dim=None, **kw):
     """Factory in the spirit of milvus_retrieval.py:143-162 (unknown type -> ValueError)."""
     if model_type == "densenet121":
         return DenseNet121(embedding_dim=embedding_dim, **kw), 224
+    if model_type == "convnextv2":
+        return ConvNeXtV2(embedding_dim=embedding_dim, **kw), 384
     raise ValueError(f"Unknown model type: {model_type}")

@@ -199,6 +199,15 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
                                  const float *shift, int64_t n, int h, int wd, float *y,
                                  void *stream);
 
+/*
+ * ConvNeXt block front end: y = permute_NHWC(depthwise_conv7x7(x) + bias), pad 3, stride 1.
+ * Replaces conv_dw + x.permute(0, 2, 3, 1) of timm's ConvNeXtBlock (the convnextv2_base backbone
+ * of model.py:96-100).  x: device NCHW fp32 [n, c, h, w]; w: device [c, 1, 7, 7]; bias: device [c]
+ * or NULL; y: device NHWC fp32 [n, h, w, c].
+ */
+int mirx_dwconv7x7_nchw_to_nhwc(const float *x, const float *w, const float *bias, int64_t n, int c, int h,
+                                int wd, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
