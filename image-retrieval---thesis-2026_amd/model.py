@@ -435,10 +435,257 @@ class ConvNeXtV2(nn.Module):
         return F.normalize(x, dim=1)
 
 
+# =================================================================================================
+# DINOv2 ViT-B/14 (reference model.py:448-494 and nih_multilabel_retrieval.py:170-221 around timm
+# 'vit_base_patch14_dinov2.lvd142m', num_classes=0).  Module tree reproduces timm's parameter names
+# (cls_token, pos_embed, patch_embed.proj, blocks.N.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,
+# mlp.fc1,mlp.fc2,ls2.gamma}, norm) so `backbone.*` checkpoints load unchanged.
+# =================================================================================================
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init=1e-5):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class _VitAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])      # softmax(q k^T / sqrt(d)) v
+        return self.proj(a.transpose(1, 2).reshape(b, n, c))
+
+
+class _VitMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _VitBlock(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _VitAttention(dim, heads)
+        self.ls1 = _LayerScale(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _VitMlp(dim, 4 * dim)
+        self.ls2 = _LayerScale(dim)
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class _Dinov2Backbone(nn.Module):
+    """timm VisionTransformer surface used by the reference: forward(x) -> CLS feature [B,C],
+    forward_features(x) -> tokens [B,1+N,C], .blocks, .norm, .num_features."""
+
+    def __init__(self, img_size=518, patch=14, dim=768, depth=12, heads=12):
+        super().__init__()
+        self.num_features = dim
+        self.patch_size = patch
+        self.grid = img_size // patch
+        self.patch_embed = _PatchEmbed(dim, patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(0.02 * torch.randn(1, 1 + self.grid * self.grid, dim))
+        self.blocks = nn.Sequential(*[_VitBlock(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def _pos(self, gh, gw):
+        if gh == self.grid and gw == self.grid:
+            return self.pos_embed
+        # other input sizes: bicubic resampling of the patch grid (timm resample_abs_pos_embed)
+        cls, grid = self.pos_embed[:, :1], self.pos_embed[:, 1:]
+        grid = grid.reshape(1, self.grid, self.grid, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(gh, gw), mode="bicubic", antialias=True, align_corners=False)
+        return torch.cat([cls, grid.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], dim=1)
+
+    def forward_features(self, x):
+        gh, gw = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self._pos(gh, gw)
+        return self.norm(self.blocks(x))
+
+    def forward(self, x):
+        return self.forward_features(x)[:, 0]
+
+
+def _normalize_rows(x):
+    if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32:
+        from .index import l2_normalize_
+        return l2_normalize_(x.contiguous().clone())
+    return F.normalize(x, dim=1)
+
+
+class DinoV2(nn.Module):
+    """Reference model.py:448-494 (`backbone`, `fc`; the last `unfreeze_blocks` blocks + final norm
+    trainable, the rest frozen)."""
+
+    def __init__(self, model_name="vit_base_patch14_dinov2.lvd142m", pretrained=False, embedding_dim=None,
+                 unfreeze_blocks=3, weights=None, img_size=518):
+        super().__init__()
+        if pretrained and weights is None:
+            raise RuntimeError("pretrained=True needs a download in the reference (model.py:459-463); "
+                               "pass weights=<state dict or path> instead")
+        if model_name != "vit_base_patch14_dinov2.lvd142m":
+            raise ValueError(f"Unknown DINOv2 backbone: {model_name}")
+        self.backbone = _Dinov2Backbone(img_size=img_size)
+        for p in self.backbone.parameters():
+            p.requires_grad = False
+        nb = max(0, min(unfreeze_blocks, len(self.backbone.blocks)))
+        if nb > 0:
+            for blk in list(self.backbone.blocks)[-nb:]:
+                for p in blk.parameters():
+                    p.requires_grad = True
+        for p in self.backbone.norm.parameters():
+            p.requires_grad = True
+        self.fc = nn.Linear(self.backbone.num_features, embedding_dim) if embedding_dim else None
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            for key in ("state-dict", "state_dict"):
+                if isinstance(sd, dict) and key in sd:
+                    sd = sd[key]
+            self.load_state_dict(sd, strict=False)
+
+    def forward(self, x):
+        x = torch.flatten(self.backbone(x), 1)
+        if self.fc:
+            x = self.fc(x)
+        return _normalize_rows(x)
+
+
+class DINOv2MultiLabelRetrievalModel(nn.Module):
+    """Reference nih_multilabel_retrieval.py:170-221: dict with cls_embedding / projection /
+    embedding (unit norm, 256-d) / logits."""
+
+    def __init__(self, num_labels=14, backbone_name="vit_base_patch14_dinov2.lvd142m", pretrained=False, img_size=518):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained=True needs a download in the reference; load a state dict instead")
+        if backbone_name != "vit_base_patch14_dinov2.lvd142m":
+            raise ValueError(f"Unknown DINOv2 backbone: {backbone_name}")
+        self.backbone = _Dinov2Backbone(img_size=img_size)
+        self.projection_head = nn.Sequential(nn.Linear(self.backbone.num_features, 512), nn.GELU(), nn.Linear(512, 256))
+        self.classification_head = nn.Linear(256, num_labels)
+
+    def forward(self, images):
+        cls_embedding = self.backbone.forward_features(images)[:, 0]
+        projection = self.projection_head(cls_embedding)
+        return {"cls_embedding": cls_embedding, "projection": projection,
+                "embedding": _normalize_rows(projection), "logits": self.classification_head(projection)}
+
+
+class ConvNeXtV2MultiLabelRetrievalModel(nn.Module):
+    """Reference nih_multilabel_retrieval.py:224-257."""
+
+    def __init__(self, num_labels=14, backbone_name="convnextv2_base.fcmae_ft_in22k_in1k_384", pretrained=False):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained=True needs a download in the reference; load a state dict instead")
+        self.backbone = _ConvNeXtV2Backbone()
+        self.projection_head = nn.Sequential(nn.Linear(self.backbone.num_features, 512), nn.GELU(), nn.Linear(512, 256))
+        self.classification_head = nn.Linear(256, num_labels)
+
+    def forward(self, images):
+        features = self.backbone(images)
+        projection = self.projection_head(features)
+        return {"backbone_embedding": features, "projection": projection,
+                "embedding": _normalize_rows(projection), "logits": self.classification_head(projection)}
+
+
+# =================================================================================================
+# MedSigLIP (reference model.py:536-634): SigLIP so400m vision tower -> pooler_output ->
+# Linear(h,512)-LayerNorm-ReLU-Linear(512,embed_dim) -> L2 normalise.  The reference takes the tower
+# from `AutoModel.from_pretrained("google/medsiglip-448").vision_model` (a download); here the same
+# transformers class is built from a LOCAL config, so `backbone.*` / `projection.*` checkpoints
+# load unchanged and nothing is fetched.
+# =================================================================================================
+MEDSIGLIP_VISION = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+                        image_size=448, patch_size=14)
+
+
+class MedSigLIP(nn.Module):
+    def __init__(self, model_name="google/medsiglip-448", embed_dim=512, unfreeze_layers=2, vision_config=None,
+                 weights=None):
+        super().__init__()
+        try:
+            from transformers import SiglipVisionConfig, SiglipVisionModel
+        except Exception as e:  # pragma: no cover
+            raise RuntimeError("MedSigLIP needs the `transformers` package (a reference dependency)") from e
+        cfg = SiglipVisionConfig(**(vision_config or MEDSIGLIP_VISION))
+        cfg._attn_implementation = "eager"          # the reference forces eager attention (model.py:546-551)
+        tower = SiglipVisionModel(cfg)
+        self.backbone = getattr(tower, "vision_model", tower)   # transformers < 5 wraps the tower once more
+        for p in self.backbone.parameters():
+            p.requires_grad = False
+        if unfreeze_layers > 0:
+            for layer in self.backbone.encoder.layers[-unfreeze_layers:]:
+                for p in layer.parameters():
+                    p.requires_grad = True
+            for p in self.backbone.post_layernorm.parameters():
+                p.requires_grad = True
+        hidden = self.backbone.config.hidden_size
+        self.projection = nn.Sequential(nn.Linear(hidden, 512), nn.LayerNorm(512), nn.ReLU(), nn.Linear(512, embed_dim))
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            for key in ("state-dict", "state_dict"):
+                if isinstance(sd, dict) and key in sd:
+                    sd = sd[key]
+            self.load_state_dict(sd, strict=False)
+
+    def ensure_eager_attention(self):
+        """Kept for callers (milvus_retrieval.py:172); the tower is built eager already."""
+        self.backbone.config._attn_implementation = "eager"
+
+    def verify_attention_output(self, device="cuda"):
+        self.eval()
+        size = self.backbone.config.image_size
+        with torch.no_grad():
+            out = self.backbone(pixel_values=torch.randn(1, 3, size, size, device=device), output_attentions=True,
+                                return_dict=True)
+        return out.attentions is not None and len(out.attentions) > 0 and out.attentions[0].numel() > 0
+
+    def forward(self, x):
+        features = self.backbone(pixel_values=x).pooler_output
+        return _normalize_rows(self.projection(features))
+
+
 def build_model(model_type, embedding_dim=None, **kw):
     """Factory in the spirit of milvus_retrieval.py:143-162 (unknown type -> ValueError)."""
     if model_type == "densenet121":
         return DenseNet121(embedding_dim=embedding_dim, **kw), 224
     if model_type == "convnextv2":
         return ConvNeXtV2(embedding_dim=embedding_dim, **kw), 384
+    if model_type == "dinov2":
+        return DinoV2(embedding_dim=embedding_dim, **kw), 518
+    if model_type == "medsiglip":
+        return MedSigLIP(embed_dim=embedding_dim if embedding_dim is not None else 512, **kw), 448
     raise ValueError(f"Unknown model type: {model_type}")
