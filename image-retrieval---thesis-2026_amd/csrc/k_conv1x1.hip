@@ -1,0 +1,158 @@
+// k_conv1x1.hip -- DenseNet dense-layer front half as ONE fp32 MFMA kernel:
+//     y = act_out( W * act_in(x) + bias )        (1x1 convolution = GEMM over channels)
+// with act_in(x)[k] = relu(x[k] * scale[k] + shift[k]) applied while the activation tile is staged
+// (norm1 + relu1 of torchvision's _DenseLayer) and act_out = relu (norm2's shift is the bias, its
+// scale is folded into W by the caller) -- so the concatenated feature buffer is read ONCE per layer
+// instead of three times (BN pass, ReLU pass, conv read).  Replaces norm1 -> relu1 -> conv1 -> norm2
+// -> relu2 of model.py:53's densenet121 (and, with the prologue off, the transition 1x1 conv).
+//
+// x is the channel-prefix view of the block buffer: image b, channel k, pixel p at
+// x[b * x_batch_stride + k * hw + p].  y is packed NCHW [n, cout, hw].
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD): workgroup tile = 128 output
+// channels x 64 pixels, 4 waves as 2 (channels) x 2 (pixels), K staged 32 channels at a time through
+// a double-buffered LDS image (A = W^T [k][128], B = act [k][64]); both operand reads are one
+// ds_read_b32 per lane with consecutive lanes on consecutive words (conflict-free).
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int CM = 128;   // output channels per workgroup
+constexpr int CP = 64;    // pixels per workgroup
+constexpr int KC = 32;    // input channels per stage
+
+template <bool VEC4, bool PROLOGUE, bool RELU_OUT>
+__global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, int64_t xbs, int cin,
+                                                 const float *__restrict__ scale,
+                                                 const float *__restrict__ shift,
+                                                 const float *__restrict__ wt, const float *__restrict__ bias,
+                                                 int64_t n, int hw, int cout, float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float sA[2][KC][CM];
+    __shared__ __attribute__((aligned(16))) float sB[2][KC][CP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t total = n * (int64_t)hw;
+    const int64_t p0 = (int64_t)blockIdx.x * CP;
+    const int co0 = blockIdx.y * CM;
+
+    // staging assignments
+    const int a_k = threadIdx.x >> 5, a_m4 = threadIdx.x & 31;            // A: rows a_k + 8 i, 4 channels at 4 a_m4
+    const int b_k = threadIdx.x >> 4, b_p4 = threadIdx.x & 15;            // B (VEC4): rows b_k + 16 i, 4 pixels at 4 b_p4
+    int64_t b_src = -1;                                                   // element offset of this thread's pixel group
+    if (VEC4) {
+        const int64_t pp = p0 + 4 * b_p4;
+        if (pp < total) b_src = (pp / hw) * xbs + (pp % hw);
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < KC / 8; ++i) {
+            const int k = a_k + 8 * i;
+            const float4 v = *reinterpret_cast<const float4 *>(wt + (int64_t)(k0 + k) * cout + co0 + 4 * a_m4);
+            *reinterpret_cast<float4 *>(&sA[buf][k][4 * a_m4]) = v;
+        }
+        if (VEC4) {
+#pragma unroll
+            for (int i = 0; i < KC / 16; ++i) {
+                const int k = b_k + 16 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_src >= 0) {
+                    v = *reinterpret_cast<const float4 *>(x + b_src + (int64_t)(k0 + k) * hw);
+                    if (PROLOGUE) {
+                        const float sc = scale[k0 + k], sh = shift[k0 + k];
+                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+                    }
+                }
+                *reinterpret_cast<float4 *>(&sB[buf][k][4 * b_p4]) = v;
+            }
+        } else {
+            // hw not a multiple of 4 (7x7 maps): scalar gather, 8 elements per thread
+#pragma unroll
+            for (int i = 0; i < KC * CP / 256; ++i) {
+                const int e = threadIdx.x + 256 * i, k = e / CP, p = e % CP;
+                const int64_t pp = p0 + p;
+                float v = 0.f;
+                if (pp < total) {
+                    v = x[(pp / hw) * xbs + (int64_t)(k0 + k) * hw + (pp % hw)];
+                    if (PROLOGUE) v = fmaxf(fmaf(v, scale[k0 + k], shift[k0 + k]), 0.f);
+                }
+                sB[buf][k][p] = v;
+            }
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int nk = cin / KC;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();                                   // stage kt visible; buffer cur^1 free
+        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * KC);
+        const int kh = lane >> 5, nn = wn * 32 + (lane & 31), m0 = wm * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            const float b = sB[cur][2 * kk + kh][nn];
+            const float a0 = sA[cur][2 * kk + kh][m0];
+            const float a1 = sA[cur][2 * kk + kh][m0 + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        }
+    }
+
+    // epilogue: register r of tile mi = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
+    // pixel p0 + 32 wn + (lane & 31)
+    const int64_t pp = p0 + wn * 32 + (lane & 31);
+    if (pp >= total) return;
+    const int64_t bimg = pp / hw, off = pp % hw;
+    float *yo = y + bimg * (int64_t)cout * hw + off;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[mi][r] + (bias ? bias[ch] : 0.f);
+            if (RELU_OUT) v = fmaxf(v, 0.f);
+            yo[(int64_t)ch * hw] = v;
+        }
+}
+
+template <bool VEC4>
+hipError_t launch_v(const float *x, int64_t xbs, int cin, const float *scale, const float *shift, const float *wt,
+                    const float *bias, int64_t n, int hw, int cout, int relu_out, float *y, hipStream_t st) {
+    const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
+    if (scale) {
+        if (relu_out)
+            hipLaunchKernelGGL((k_conv1x1<VEC4, true, true>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+        else
+            hipLaunchKernelGGL((k_conv1x1<VEC4, true, false>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+    } else {
+        if (relu_out)
+            hipLaunchKernelGGL((k_conv1x1<VEC4, false, true>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+        else
+            hipLaunchKernelGGL((k_conv1x1<VEC4, false, false>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                          const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
+                          hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (cin % KC || cout % CM) return hipErrorInvalidValue;
+    if ((hw & 3) == 0 && (xbs & 3) == 0)
+        return launch_v<true>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+    return launch_v<false>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+}
+
+}  // namespace mirx

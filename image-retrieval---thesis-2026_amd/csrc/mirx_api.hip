@@ -670,6 +670,18 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
     return MIRX_OK;
 }
 
+int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const float *scale, const float *shift,
+                         const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
+                         void *stream) {
+    MIRX_CHECK(x && wt && y && n >= 0 && hw >= 1, "conv1x1: null argument");
+    MIRX_CHECK((scale == nullptr) == (shift == nullptr), "conv1x1: scale and shift go together");
+    MIRX_CHECK(cin >= 32 && cin % 32 == 0 && cout >= 128 && cout % 128 == 0, "conv1x1: cin % 32 and cout % 128 must be 0");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1: batch stride smaller than cin * hw");
+    MIRX_HIP(launch_conv1x1(x, x_batch_stride, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y,
+                            reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_dwconv7x7_nchw_to_nhwc(const float *x, const float *w, const float *bias, int64_t n, int c, int h,
                                 int wd, float *y, void *stream) {
     MIRX_CHECK(x && w && y && n >= 0 && c >= 1 && h >= 1 && wd >= 1, "dwconv7x7: bad argument");

@@ -26,6 +26,11 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 
+// ---- k_conv1x1.hip ----------------------------------------------------------------------
+hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                          const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
+                          hipStream_t st);
+
 // ---- k_convnext.hip ---------------------------------------------------------------------
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
                           float *y, hipStream_t st);

@@ -88,7 +88,7 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
     return out
 
 
-def _dense_block_fused(block, x, cache):
+def _dense_block_fused(block, x, cache, use_hip_conv1x1=True):
     """Inference path of one dense block (CUDA, eval):
        per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
@@ -99,7 +99,16 @@ def _dense_block_fused(block, x, cache):
     buf[:, : block.cin] = x
     c = block.cin
     for name, layer in block.items():
-        sc1, sh1, w1, b1, ones = cache[name]
+        sc1, sh1, w1, b1, ones, w1t = cache[name]
+        if use_hip_conv1x1:
+            # norm1 + relu1 + conv1 + norm2 + relu2 in ONE fp32-MFMA pass over the buffer prefix
+            y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
+            _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1), _ptr(w1t),
+                                                _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
+                       "mirx_conv1x1_bn_relu")
+            buf[:, c: c + GROWTH] = F.conv2d(y, layer.conv2.weight, None, padding=1)
+            c += GROWTH
+            continue
         y = _fused_bn_relu(lib, buf, c, sc1, sh1)
         y = F.conv2d(y, w1)                       # norm2's scale is folded into w1 ...
         # ... and its shift + relu2 run as ONE in-place HIP pass (a conv bias would cost a separate
@@ -112,11 +121,11 @@ def _dense_block_fused(block, x, cache):
     return buf
 
 
-def _transition_fused(tr, buf, cache):
+def _transition_fused(tr, buf, cache, use_hip_conv1x1=True):
     """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
     the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
     lib = _lib.load()
-    sc, sh = cache
+    sc, sh, wt = cache
     b, c, h, w = buf.shape
     if h % 2 or w % 2:
         return tr.pool(tr.conv(F.relu(F.batch_norm(buf, tr.norm.running_mean, tr.norm.running_var,
@@ -124,6 +133,12 @@ def _transition_fused(tr, buf, cache):
     pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
     _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled),
                                          _stream(buf.device)), "mirx_bn_relu_avgpool2")
+    if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
+        out = torch.empty((b, wt.shape[1], h // 2, w // 2), dtype=torch.float32, device=buf.device)
+        _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(wt), None, b,
+                                            (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out), _stream(buf.device)),
+                   "mirx_conv1x1_bn_relu")
+        return out
     return F.conv2d(pooled, tr.conv.weight)
 
 
@@ -193,6 +208,7 @@ class DenseNet121(nn.Module):
         out_features = embedding_dim if embedding_dim else in_features
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
+        self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
@@ -231,10 +247,12 @@ class DenseNet121(nn.Module):
                     sc1, sh1 = _bn_affine(layer.norm1)
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
-                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2))
+                    w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t)
                 cache[name] = blk
             elif name.startswith("transition"):
-                cache[name] = _bn_affine(m.norm)
+                wt = m.conv.weight.detach().float()
+                cache[name] = _bn_affine(m.norm) + (wt.view(wt.shape[0], wt.shape[1]).t().contiguous(),)
         cache["norm0"] = _bn_affine(f.norm0)
         cache["norm5"] = _bn_affine(f.norm5)
         self._infer_cache = cache
@@ -258,9 +276,9 @@ class DenseNet121(nn.Module):
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
         for name, m in f.named_children():
             if name.startswith("denseblock"):
-                x = _dense_block_fused(m, x, cache[name])
+                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1)
             elif name.startswith("transition"):
-                x = _transition_fused(m, x, cache[name])
+                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1)
         return x
 
     def _head_fused(self, fmap, normalize):

@@ -200,6 +200,20 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
                                  void *stream);
 
 /*
+ * Fused 1x1 convolution of a DenseNet dense layer / transition (fp32 MFMA):
+ *     y[b, o, p] = act_out( sum_k wt[k, o] * act_in(x[b, k, p]) + bias[o] )
+ * act_in(v) = relu(v * scale[k] + shift[k]) when scale != NULL (norm1 + relu1), identity otherwise;
+ * act_out = relu when relu_out != 0 (relu2; norm2 = bias + a scale folded into wt by the caller).
+ * Replaces norm1 -> relu1 -> conv1 -> norm2 -> relu2 of torchvision's _DenseLayer (model.py:53) in one
+ * pass over the concatenated features.  x: channel-prefix view, image stride x_batch_stride floats,
+ * cin % 32 == 0; wt: device [cin, cout] (the conv weight TRANSPOSED), cout % 128 == 0; bias: device
+ * [cout] or NULL; y: device packed NCHW [n, cout, hw].
+ */
+int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const float *scale, const float *shift,
+                         const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
+                         void *stream);
+
+/*
  * ConvNeXt block front end: y = permute_NHWC(depthwise_conv7x7(x) + bias), pad 3, stride 1.
  * Replaces conv_dw + x.permute(0, 2, 3, 1) of timm's ConvNeXtBlock (the convnextv2_base backbone
  * of model.py:96-100).  x: device NCHW fp32 [n, c, h, w]; w: device [c, 1, 7, 7]; bias: device [c]

@@ -109,3 +109,38 @@ def test_fused_elementwise_kernels():
                                              b, c, h, w, ctypes.c_void_p(yp.data_ptr()), None) == 0
             torch.cuda.synchronize()
             torch.testing.assert_close(yp.cpu(), want_p, atol=1e-6, rtol=1e-6)
+
+
+def test_fused_conv1x1_kernel():
+    """mirx_conv1x1_bn_relu against torch: prologue/epilogue variants, 7x7 maps (scalar staging path),
+    partial last tiles, channel-prefix views of a wider buffer."""
+    import ctypes
+    from mirx import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    for (b, ctot, cin, hw_shape, cout, prologue, relu_out) in (
+            (3, 256, 96, (56, 56), 128, True, True), (5, 1024, 992, (7, 7), 128, True, True),
+            (2, 512, 512, (14, 14), 256, False, False), (2, 64, 64, (10, 6), 128, True, False)):
+        h, w = hw_shape
+        buf = torch.randn(b, ctot, h, w, generator=g)
+        wt4 = 0.1 * torch.randn(cout, cin, 1, 1, generator=g)
+        sc, sh = 0.5 + torch.rand(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
+        bias = 0.2 * torch.randn(cout, generator=g)
+        xin = buf[:, :cin]
+        if prologue:
+            xin = torch.relu(xin * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        want = torch.nn.functional.conv2d(xin, wt4, bias)
+        if relu_out:
+            want = torch.relu(want)
+        bg = buf.cuda()
+        wtg = wt4.view(cout, cin).t().contiguous().cuda()
+        scg, shg, biasg = sc.cuda(), sh.cuda(), bias.cuda()
+        y = torch.empty((b, cout, h, w), device="cuda")
+        rc = lib.mirx_conv1x1_bn_relu(ctypes.c_void_p(bg.data_ptr()), ctot * h * w, cin,
+                                      ctypes.c_void_p(scg.data_ptr()) if prologue else None,
+                                      ctypes.c_void_p(shg.data_ptr()) if prologue else None,
+                                      ctypes.c_void_p(wtg.data_ptr()), ctypes.c_void_p(biasg.data_ptr()), b, h * w, cout,
+                                      1 if relu_out else 0, ctypes.c_void_p(y.data_ptr()), None)
+        assert rc == 0, lib.mirx_last_error()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y.cpu(), want, atol=1e-4, rtol=1e-4)

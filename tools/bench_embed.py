@@ -8,7 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mirx.model import ConvNeXtV2, DenseNet121  # noqa: E402
+from mirx.model import ConvNeXtV2, DenseNet121, DinoV2  # noqa: E402
 
 
 def main():
@@ -19,15 +19,19 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-hip-stem", action="store_true")
-    ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2"])
+    ap.add_argument("--no-hip-conv1x1", action="store_true")
+    ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2", "dinov2"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     if a.model == "convnextv2":
         m = ConvNeXtV2(embedding_dim=256).eval().to(dev)
+    elif a.model == "dinov2":
+        m = DinoV2(embedding_dim=256).eval().to(dev)
     else:
         m = DenseNet121().eval().to(dev)
         m.use_hip_stem = not a.no_hip_stem
+        m.use_hip_conv1x1 = not a.no_hip_conv1x1
     if a.channels_last:
         m = m.to(memory_format=torch.channels_last)
     x = torch.randn(a.batch, 3, a.size, a.size, device=dev)
