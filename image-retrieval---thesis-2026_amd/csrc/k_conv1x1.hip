@@ -22,15 +22,16 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int CM = 128;   // output channels per workgroup
-constexpr int CP = 64;    // pixels per workgroup
 constexpr int KC = 32;    // input channels per stage
 
-template <bool VEC4, bool PROLOGUE, bool RELU_OUT>
+// NREP = 32-pixel tiles per wave: workgroup tile = 128 channels x (64 * NREP) pixels
+template <bool VEC4, bool PROLOGUE, bool RELU_OUT, int NREP>
 __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, int64_t xbs, int cin,
                                                  const float *__restrict__ scale,
                                                  const float *__restrict__ shift,
                                                  const float *__restrict__ wt, const float *__restrict__ bias,
                                                  int64_t n, int hw, int cout, float *__restrict__ y) {
+    constexpr int CP = 64 * NREP;
     __shared__ __attribute__((aligned(16))) float sA[2][KC][CM];
     __shared__ __attribute__((aligned(16))) float sB[2][KC][CP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -41,10 +42,14 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
 
     // staging assignments
     const int a_k = threadIdx.x >> 5, a_m4 = threadIdx.x & 31;            // A: rows a_k + 8 i, 4 channels at 4 a_m4
-    const int b_k = threadIdx.x >> 4, b_p4 = threadIdx.x & 15;            // B (VEC4): rows b_k + 16 i, 4 pixels at 4 b_p4
-    int64_t b_src = -1;                                                   // element offset of this thread's pixel group
+    constexpr int PG = CP / 4;                                            // float4 pixel groups per row
+    const int b_k = threadIdx.x / PG, b_p4 = threadIdx.x % PG;            // B (VEC4): rows b_k + (256/PG) i, 4 pixels at 4 b_p4
+    int64_t b_src = -1;                                                   // element offset of this thread's pixel (group)
     if (VEC4) {
         const int64_t pp = p0 + 4 * b_p4;
+        if (pp < total) b_src = (pp / hw) * xbs + (pp % hw);
+    } else {
+        const int64_t pp = p0 + (threadIdx.x % CP);                       // scalar path: one pixel per thread
         if (pp < total) b_src = (pp / hw) * xbs + (pp % hw);
     }
     auto stage = [&](int buf, int k0) {
@@ -56,8 +61,8 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         }
         if (VEC4) {
 #pragma unroll
-            for (int i = 0; i < KC / 16; ++i) {
-                const int k = b_k + 16 * i;
+            for (int i = 0; i < KC * PG / 256; ++i) {
+                const int k = b_k + (256 / PG) * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (b_src >= 0) {
                     v = *reinterpret_cast<const float4 *>(x + b_src + (int64_t)(k0 + k) * hw);
@@ -73,11 +78,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
             // hw not a multiple of 4 (7x7 maps): scalar gather, 8 elements per thread
 #pragma unroll
             for (int i = 0; i < KC * CP / 256; ++i) {
-                const int e = threadIdx.x + 256 * i, k = e / CP, p = e % CP;
-                const int64_t pp = p0 + p;
+                const int k = threadIdx.x / CP + (256 / CP) * i, p = threadIdx.x % CP;
                 float v = 0.f;
-                if (pp < total) {
-                    v = x[(pp / hw) * xbs + (int64_t)(k0 + k) * hw + (pp % hw)];
+                if (b_src >= 0) {
+                    v = x[b_src + (int64_t)(k0 + k) * hw];
                     if (PROLOGUE) v = fmaxf(fmaf(v, scale[k0 + k], shift[k0 + k]), 0.f);
                 }
                 sB[buf][k][p] = v;
@@ -85,11 +89,13 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[2][NREP];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        for (int ni = 0; ni < NREP; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nk = cin / KC;
     stage(0, 0);
@@ -97,49 +103,56 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         const int cur = kt & 1;
         __syncthreads();                                   // stage kt visible; buffer cur^1 free
         if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * KC);
-        const int kh = lane >> 5, nn = wn * 32 + (lane & 31), m0 = wm * 64 + (lane & 31);
+        const int kh = lane >> 5, nn = wn * 32 * NREP + (lane & 31), m0 = wm * 64 + (lane & 31);
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            const float b = sB[cur][2 * kk + kh][nn];
+            float bv[NREP];
+#pragma unroll
+            for (int ni = 0; ni < NREP; ++ni) bv[ni] = sB[cur][2 * kk + kh][nn + 32 * ni];
             const float a0 = sA[cur][2 * kk + kh][m0];
             const float a1 = sA[cur][2 * kk + kh][m0 + 32];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NREP; ++ni) {
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[ni], acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[ni], acc[1][ni], 0, 0, 0);
+            }
         }
     }
 
-    // epilogue: register r of tile mi = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
-    // pixel p0 + 32 wn + (lane & 31)
-    const int64_t pp = p0 + wn * 32 + (lane & 31);
-    if (pp >= total) return;
-    const int64_t bimg = pp / hw, off = pp % hw;
-    float *yo = y + bimg * (int64_t)cout * hw + off;
+    // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
+    // pixel p0 + 32 NREP wn + 32 ni + (lane & 31)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < NREP; ++ni) {
+        const int64_t pp = p0 + wn * 32 * NREP + 32 * ni + (lane & 31);
+        if (pp >= total) continue;
+        const int64_t bimg = pp / hw, off = pp % hw;
+        float *yo = y + bimg * (int64_t)cout * hw + off;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = acc[mi][r] + (bias ? bias[ch] : 0.f);
-            if (RELU_OUT) v = fmaxf(v, 0.f);
-            yo[(int64_t)ch * hw] = v;
-        }
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[mi][ni][r] + (bias ? bias[ch] : 0.f);
+                if (RELU_OUT) v = fmaxf(v, 0.f);
+                yo[(int64_t)ch * hw] = v;
+            }
+    }
 }
 
-template <bool VEC4>
+template <bool VEC4, int NREP>
 hipError_t launch_v(const float *x, int64_t xbs, int cin, const float *scale, const float *shift, const float *wt,
                     const float *bias, int64_t n, int hw, int cout, int relu_out, float *y, hipStream_t st) {
+    constexpr int CP = 64 * NREP;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
+#define MIRX_C1(P, R)                                                                                       \
+    hipLaunchKernelGGL((k_conv1x1<VEC4, P, R, NREP>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, \
+                       hw, cout, y)
     if (scale) {
-        if (relu_out)
-            hipLaunchKernelGGL((k_conv1x1<VEC4, true, true>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
-        else
-            hipLaunchKernelGGL((k_conv1x1<VEC4, true, false>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+        if (relu_out) MIRX_C1(true, true); else MIRX_C1(true, false);
     } else {
-        if (relu_out)
-            hipLaunchKernelGGL((k_conv1x1<VEC4, false, true>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
-        else
-            hipLaunchKernelGGL((k_conv1x1<VEC4, false, false>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, hw, cout, y);
+        if (relu_out) MIRX_C1(false, true); else MIRX_C1(false, false);
     }
+#undef MIRX_C1
     return hipGetLastError();
 }
 
@@ -150,9 +163,11 @@ hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *sca
                           hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM) return hipErrorInvalidValue;
+    // NREP = 1 (64-pixel tiles, 48 KiB LDS, 3 workgroups per CU) measured faster than NREP = 2
+    // (128-pixel tiles, 2 per CU) on every DenseNet-121 layer shape: 13.6k vs 13.3k img/s end to end
     if ((hw & 3) == 0 && (xbs & 3) == 0)
-        return launch_v<true>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
-    return launch_v<false>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+        return launch_v<true, 1>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+    return launch_v<false, 1>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
 }
 
 }  // namespace mirx
