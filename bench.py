@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2516.6
+MFMA_F32_PEAK_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD (guide, chip-level table)
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
@@ -74,6 +75,30 @@ def build_shard(index, lo, hi, dim, device, chunk=1 << 16):
         rows = gallery_chunk(c, chunk, dim, device)
         a, b = max(lo, c * chunk), min(hi, (c + 1) * chunk)
         index.add(rows[a - c * chunk: b - c * chunk], torch.arange(a, b, device=device))
+
+
+def gemm_traffic_from_profile(args, world, q_local):
+    """HBM-side bytes per launch of the filter GEMM from the committed PMC passes
+    (profiles/r01_gemm_pmc.csv: separate FETCH_SIZE / WRITE_SIZE runs of tools/bench_search.py --q 4096;
+    FETCH_SIZE is in KB and counts half the bytes of wide coalesced loads on gfx950).  Only valid for
+    the configuration those passes ran on; otherwise null."""
+    if not (world == 1 and q_local == 4096 and args.gallery == 1_000_000 and args.dim == 1024):
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    fetch, write = [], []
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if "k_gemm<256, 0" in r["Kernel_Name"]:
+                if r["Counter_Name"] == "FETCH_SIZE":
+                    fetch.append(float(r["Counter_Value"]))
+                elif r["Counter_Name"] == "WRITE_SIZE":
+                    write.append(float(r["Counter_Value"]))
+    if not fetch or not write:
+        return None
+    return (2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0
 
 
 def cpu_baseline(index, model, args, dev):
@@ -177,6 +202,25 @@ def main():
 
     total_q = world * q_local * args.steps
     stats = index.last_stats()
+    embed_roof = None
+    if rank == 0 and not args.search_only:
+        # calibration pass OUTSIDE the timed region: HIP events around every launch of the embed
+        # stage's dominant hand-written kernel (the fused fp32-MFMA 1x1 convolution)
+        model.conv1x1_timer = []
+        with torch.no_grad():
+            model(pool[0])
+        torch.cuda.synchronize(dev)
+        ms = sum(a.elapsed_time(b) for a, b, _ in model.conv1x1_timer)
+        fl = sum(f for _, _, f in model.conv1x1_timer)
+        nl = len(model.conv1x1_timer)
+        model.conv1x1_timer = None
+        if ms > 0:
+            ach = fl / (ms * 1e-3) / 1e12
+            embed_roof = {"bound": "mfma", "kernel": "mirx::k_conv1x1 (fused BN+ReLU+1x1 conv+BN+ReLU, fp32 MFMA), "
+                          f"{nl} launches of one {args.embed_batch}-image forward", "dtype": "f32",
+                          "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "flop_per_forward": fl, "ms_per_forward": ms,
+                          "traffic": None}
     if rank == 0:
         dimp = (args.dim + 63) // 64 * 64
         flop = 2.0 * (world * q_local) * (hi - lo) * dimp
@@ -208,6 +252,9 @@ def main():
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                          "flop_per_launch": flop, "avg_launch_ms": avg_gemm_ms},
         }
+        if embed_roof is not None:
+            line["roofline_embed"] = embed_roof
+        line["roofline"]["traffic"] = gemm_traffic_from_profile(args, world, q_local)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(index, model, args, dev)
         print(json.dumps(line), flush=True)

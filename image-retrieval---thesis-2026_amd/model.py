@@ -79,6 +79,21 @@ class _DenseBlock(nn.ModuleDict):
         return buf
 
 
+def _timer_start(timer):
+    """Optional per-launch timing of the fused conv kernel (bench.py's calibration pass)."""
+    if timer is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    return ev
+
+
+def _timer_stop(timer, ev, flops):
+    if timer is not None:
+        ev[1].record()
+        timer.append((ev[0], ev[1], flops))
+
+
 def _fused_bn_relu(lib, buf, c, scale, shift):
     """relu(bn(buf[:, :c])) -> packed [B, c, H, W] in one HIP pass over the channel-prefix view."""
     b, ctot, h, w = buf.shape
@@ -88,7 +103,7 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
     return out
 
 
-def _dense_block_fused(block, x, cache, use_hip_conv1x1=True):
+def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None):
     """Inference path of one dense block (CUDA, eval):
        per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
@@ -103,9 +118,11 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True):
         if use_hip_conv1x1:
             # norm1 + relu1 + conv1 + norm2 + relu2 in ONE fp32-MFMA pass over the buffer prefix
             y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
+            ev = _timer_start(timer)
             _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1), _ptr(w1t),
                                                 _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
                        "mirx_conv1x1_bn_relu")
+            _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
             buf[:, c: c + GROWTH] = F.conv2d(y, layer.conv2.weight, None, padding=1)
             c += GROWTH
             continue
@@ -121,7 +138,7 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True):
     return buf
 
 
-def _transition_fused(tr, buf, cache, use_hip_conv1x1=True):
+def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None):
     """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
     the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
     lib = _lib.load()
@@ -135,9 +152,11 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True):
                                          _stream(buf.device)), "mirx_bn_relu_avgpool2")
     if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
         out = torch.empty((b, wt.shape[1], h // 2, w // 2), dtype=torch.float32, device=buf.device)
+        ev = _timer_start(timer)
         _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(wt), None, b,
                                             (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out), _stream(buf.device)),
                    "mirx_conv1x1_bn_relu")
+        _timer_stop(timer, ev, 2.0 * b * (h // 2) * (w // 2) * c * wt.shape[1])
         return out
     return F.conv2d(pooled, tr.conv.weight)
 
@@ -209,6 +228,7 @@ class DenseNet121(nn.Module):
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
         self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
+        self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
@@ -276,9 +296,9 @@ class DenseNet121(nn.Module):
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
         for name, m in f.named_children():
             if name.startswith("denseblock"):
-                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1)
+                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer)
             elif name.startswith("transition"):
-                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1)
+                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer)
         return x
 
     def _head_fused(self, fmap, normalize):
