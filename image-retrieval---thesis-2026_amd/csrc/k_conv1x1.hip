@@ -10,8 +10,8 @@
 // x[b * x_batch_stride + k * hw + p].  y is packed NCHW [n, cout, hw].
 //
 // v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD): workgroup tile = 128 output
-// channels x 64 pixels, 4 waves as 2 (channels) x 2 (pixels), K staged 32 channels at a time through
-// a double-buffered LDS image (A = W^T [k][128], B = act [k][64]); both operand reads are one
+// channels x 64 pixels, 4 waves as 2 (channels) x 2 (pixels), K staged 16 channels at a time through
+// a double-buffered LDS image (A = W^T [k][128], B = act [k][64], 16 channels per stage); both operand reads are one
 // ds_read_b32 per lane with consecutive lanes on consecutive words (conflict-free).
 #include "mirx_kernels.h"
 
@@ -22,10 +22,9 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int CM = 128;   // output channels per workgroup
-constexpr int KC = 32;    // input channels per stage
 
 // NREP = 32-pixel tiles per wave: workgroup tile = 128 channels x (64 * NREP) pixels
-template <bool VEC4, bool PROLOGUE, bool RELU_OUT, int NREP>
+template <bool VEC4, bool PROLOGUE, bool RELU_OUT, int NREP, int KC>
 __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, int64_t xbs, int cin,
                                                  const float *__restrict__ scale,
                                                  const float *__restrict__ shift,
@@ -60,9 +59,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
             *reinterpret_cast<float4 *>(&sA[buf][k][4 * a_m4]) = v;
         }
         if (VEC4) {
+            constexpr int BIT = (KC * PG + 255) / 256;                 // float4 groups per thread
 #pragma unroll
-            for (int i = 0; i < KC * PG / 256; ++i) {
+            for (int i = 0; i < BIT; ++i) {
                 const int k = b_k + (256 / PG) * i;
+                if (KC * PG < 256 && k >= KC) break;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (b_src >= 0) {
                     v = *reinterpret_cast<const float4 *>(x + b_src + (int64_t)(k0 + k) * hw);
@@ -139,13 +140,13 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
     }
 }
 
-template <bool VEC4, int NREP>
+template <bool VEC4, int NREP, int KC>
 hipError_t launch_v(const float *x, int64_t xbs, int cin, const float *scale, const float *shift, const float *wt,
                     const float *bias, int64_t n, int hw, int cout, int relu_out, float *y, hipStream_t st) {
     constexpr int CP = 64 * NREP;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
 #define MIRX_C1(P, R)                                                                                       \
-    hipLaunchKernelGGL((k_conv1x1<VEC4, P, R, NREP>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, \
+    hipLaunchKernelGGL((k_conv1x1<VEC4, P, R, NREP, KC>), grid, dim3(256), 0, st, x, xbs, cin, scale, shift, wt, bias, n, \
                        hw, cout, y)
     if (scale) {
         if (relu_out) MIRX_C1(true, true); else MIRX_C1(true, false);
@@ -162,12 +163,15 @@ hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *sca
                           const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
                           hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    if (cin % KC || cout % CM) return hipErrorInvalidValue;
+    if (cin % 32 || cout % CM) return hipErrorInvalidValue;
     // NREP = 1 (64-pixel tiles, 48 KiB LDS, 3 workgroups per CU) measured faster than NREP = 2
     // (128-pixel tiles, 2 per CU) on every DenseNet-121 layer shape: 13.6k vs 13.3k img/s end to end
+    // Tile choice measured on DenseNet-121 (B = 256, end-to-end img/s): 64 pixels x 16 channels per
+    // stage (24 KiB LDS, 6 workgroups per CU) 14.07k; 64 x 32: 13.62k; 64 x 8: 13.39k; 128 x 16: 13.47k;
+    // 128 x 32: 13.24k -- occupancy beats weight-tile reuse here.
     if ((hw & 3) == 0 && (xbs & 3) == 0)
-        return launch_v<true, 1>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
-    return launch_v<false, 1>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+        return launch_v<true, 1, 16>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+    return launch_v<false, 1, 16>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
 }
 
 }  // namespace mirx
