@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (all GPUs)")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--queries", type=int, default=4096, help="queries (images) per GPU per step")
-    ap.add_argument("--embed-batch", type=int, default=256)
+    ap.add_argument("--embed-batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
