@@ -33,99 +33,107 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
     constexpr int CP = 64 * NREP;
     __shared__ __attribute__((aligned(16))) float sA[2][KC][CM];
     __shared__ __attribute__((aligned(16))) float sB[2][KC][CP];
+    __shared__ float sBias[CM];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
     const int64_t p0 = (int64_t)blockIdx.x * CP;
     const int co0 = blockIdx.y * CM;
 
-    // staging assignments
-    const int a_k = threadIdx.x >> 5, a_m4 = threadIdx.x & 31;            // A: rows a_k + 8 i, 4 channels at 4 a_m4
-    constexpr int PG = CP / 4;                                            // float4 pixel groups per row
-    const int b_k = threadIdx.x / PG, b_p4 = threadIdx.x % PG;            // B (VEC4): rows b_k + (256/PG) i, 4 pixels at 4 b_p4
-    int64_t b_src = -1;                                                   // element offset of this thread's pixel (group)
-    if (VEC4) {
-        const int64_t pp = p0 + 4 * b_p4;
-        if (pp < total) b_src = (pp / hw) * xbs + (pp % hw);
-    } else {
-        const int64_t pp = p0 + (threadIdx.x % CP);                       // scalar path: one pixel per thread
-        if (pp < total) b_src = (pp / hw) * xbs + (pp % hw);
+    // Staging assignments.  A (weights): thread -> rows a_k and a_k + 8, channels 4 a_m4 .. +3.
+    // B (activations), VEC4: thread -> row b_k, pixels 4 b_p4 .. +3; scalar path (7x7 maps, hw % 4 != 0):
+    // thread -> pixel tid % 64, rows tid / 64 + 4 i.  Out-of-range pixels read pixel 0 (never stored).
+    static_assert(KC == 16 && NREP == 1, "staging below is written for 16-channel stages of 64 pixels");
+    const int a_k = threadIdx.x >> 5, a_m4 = threadIdx.x & 31;
+    const int b_k = VEC4 ? threadIdx.x >> 4 : threadIdx.x >> 6;
+    const int b_p = VEC4 ? 4 * (threadIdx.x & 15) : threadIdx.x & 63;
+    int64_t b_off = 0;
+    {
+        const int64_t pp = p0 + b_p;
+        if (pp < total) b_off = (pp / hw) * xbs + (pp % hw);
     }
-    auto stage = [&](int buf, int k0) {
-#pragma unroll
-        for (int i = 0; i < KC / 8; ++i) {
-            const int k = a_k + 8 * i;
-            const float4 v = *reinterpret_cast<const float4 *>(wt + (int64_t)(k0 + k) * cout + co0 + 4 * a_m4);
-            *reinterpret_cast<float4 *>(&sA[buf][k][4 * a_m4]) = v;
-        }
-        if (VEC4) {
-            constexpr int BIT = (KC * PG + 255) / 256;                 // float4 groups per thread
-#pragma unroll
-            for (int i = 0; i < BIT; ++i) {
-                const int k = b_k + (256 / PG) * i;
-                if (KC * PG < 256 && k >= KC) break;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b_src >= 0) {
-                    v = *reinterpret_cast<const float4 *>(x + b_src + (int64_t)(k0 + k) * hw);
-                    if (PROLOGUE) {
-                        const float sc = scale[k0 + k], sh = shift[k0 + k];
-                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-                    }
-                }
-                *reinterpret_cast<float4 *>(&sB[buf][k][4 * b_p4]) = v;
-            }
-        } else {
-            // hw not a multiple of 4 (7x7 maps): scalar gather, 8 elements per thread
-#pragma unroll
-            for (int i = 0; i < KC * CP / 256; ++i) {
-                const int k = threadIdx.x / CP + (256 / CP) * i, p = threadIdx.x % CP;
-                float v = 0.f;
-                if (b_src >= 0) {
-                    v = x[b_src + (int64_t)(k0 + k) * hw];
-                    if (PROLOGUE) v = fmaxf(fmaf(v, scale[k0 + k], shift[k0 + k]), 0.f);
-                }
-                sB[buf][k][p] = v;
-            }
-        }
-    };
+    const float *wsrc = wt + (int64_t)a_k * cout + co0 + 4 * a_m4;
+    const float *xsrc = x + b_off + (int64_t)b_k * hw;
 
-    f32x16 acc[2][NREP];
+    // Register-prefetched, branch-free pipeline: the global loads of stage kt+1 are issued before the
+    // MFMAs of stage kt and written to the idle LDS buffer after them (the last iteration re-stages its
+    // own K slice into the idle buffer, which nobody reads).
+    float4 ra0, ra1, rb;
+    float rs0, rs1, rs2, rs3, sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f, sc2 = 1.f, sh2 = 0.f, sc3 = 1.f, sh3 = 0.f;
+#define MIRX_C1_LOAD(k0)                                                                           \
+    do {                                                                                           \
+        ra0 = *reinterpret_cast<const float4 *>(wsrc + (int64_t)(k0) * cout);                      \
+        ra1 = *reinterpret_cast<const float4 *>(wsrc + (int64_t)((k0) + 8) * cout);                \
+        if (VEC4) {                                                                                \
+            rb = *reinterpret_cast<const float4 *>(xsrc + (int64_t)(k0) * hw);                     \
+            if (PROLOGUE) { sc0 = scale[(k0) + b_k]; sh0 = shift[(k0) + b_k]; }                    \
+        } else {                                                                                   \
+            rs0 = xsrc[(int64_t)(k0) * hw];                                                        \
+            rs1 = xsrc[(int64_t)((k0) + 4) * hw];                                                  \
+            rs2 = xsrc[(int64_t)((k0) + 8) * hw];                                                  \
+            rs3 = xsrc[(int64_t)((k0) + 12) * hw];                                                 \
+            if (PROLOGUE) {                                                                        \
+                sc0 = scale[(k0) + b_k]; sh0 = shift[(k0) + b_k];                                  \
+                sc1 = scale[(k0) + b_k + 4]; sh1 = shift[(k0) + b_k + 4];                          \
+                sc2 = scale[(k0) + b_k + 8]; sh2 = shift[(k0) + b_k + 8];                          \
+                sc3 = scale[(k0) + b_k + 12]; sh3 = shift[(k0) + b_k + 12];                        \
+            }                                                                                      \
+        }                                                                                          \
+    } while (0)
+#define MIRX_C1_ACT(v, sc, sh) (PROLOGUE ? fmaxf(fmaf((v), (sc), (sh)), 0.f) : (v))
+#define MIRX_C1_STORE(buf)                                                                         \
+    do {                                                                                           \
+        *reinterpret_cast<float4 *>(&sA[buf][a_k][4 * a_m4]) = ra0;                                \
+        *reinterpret_cast<float4 *>(&sA[buf][a_k + 8][4 * a_m4]) = ra1;                            \
+        if (VEC4) {                                                                                \
+            float4 v;                                                                              \
+            v.x = MIRX_C1_ACT(rb.x, sc0, sh0); v.y = MIRX_C1_ACT(rb.y, sc0, sh0);                  \
+            v.z = MIRX_C1_ACT(rb.z, sc0, sh0); v.w = MIRX_C1_ACT(rb.w, sc0, sh0);                  \
+            *reinterpret_cast<float4 *>(&sB[buf][b_k][b_p]) = v;                                   \
+        } else {                                                                                   \
+            sB[buf][b_k][b_p] = MIRX_C1_ACT(rs0, sc0, sh0);                                        \
+            sB[buf][b_k + 4][b_p] = MIRX_C1_ACT(rs1, sc1, sh1);                                    \
+            sB[buf][b_k + 8][b_p] = MIRX_C1_ACT(rs2, sc2, sh2);                                    \
+            sB[buf][b_k + 12][b_p] = MIRX_C1_ACT(rs3, sc3, sh3);                                   \
+        }                                                                                          \
+    } while (0)
+
+    f32x16 acc[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NREP; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     const int nk = cin / KC;
-    stage(0, 0);
+    if (threadIdx.x < CM) sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+    MIRX_C1_LOAD(0);
+    MIRX_C1_STORE(0);
+    const int kh = lane >> 5, nn = wn * 32 + (lane & 31), m0 = wm * 64 + (lane & 31);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();                                   // stage kt visible; buffer cur^1 free
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * KC);
-        const int kh = lane >> 5, nn = wn * 32 * NREP + (lane & 31), m0 = wm * 64 + (lane & 31);
+        const int knext = (kt + 1 < nk ? kt + 1 : kt) * KC;
+        MIRX_C1_LOAD(knext);
+        __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMAs
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            float bv[NREP];
-#pragma unroll
-            for (int ni = 0; ni < NREP; ++ni) bv[ni] = sB[cur][2 * kk + kh][nn + 32 * ni];
+            const float bv = sB[cur][2 * kk + kh][nn];
             const float a0 = sA[cur][2 * kk + kh][m0];
             const float a1 = sA[cur][2 * kk + kh][m0 + 32];
-#pragma unroll
-            for (int ni = 0; ni < NREP; ++ni) {
-                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[ni], acc[0][ni], 0, 0, 0);
-                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[ni], acc[1][ni], 0, 0, 0);
-            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
         }
+        MIRX_C1_STORE(cur ^ 1);
     }
+#undef MIRX_C1_LOAD
+#undef MIRX_C1_STORE
+#undef MIRX_C1_ACT
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 32 NREP wn + 32 ni + (lane & 31)
-#pragma unroll
-    for (int ni = 0; ni < NREP; ++ni) {
-        const int64_t pp = p0 + wn * 32 * NREP + 32 * ni + (lane & 31);
-        if (pp >= total) continue;
+    {
+        const int64_t pp = p0 + wn * 32 + (lane & 31);
+        if (pp >= total) return;
         const int64_t bimg = pp / hw, off = pp % hw;
         float *yo = y + bimg * (int64_t)cout * hw + off;
 #pragma unroll
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[mi][ni][r] + (bias ? bias[ch] : 0.f);
+                float v = acc[mi][r] + sBias[ch - co0];
                 if (RELU_OUT) v = fmaxf(v, 0.f);
                 yo[(int64_t)ch * hw] = v;
             }
