@@ -145,10 +145,18 @@ def main():
     from mirx.index import FlatIndex
     from mirx.model import DenseNet121
 
+    # MIRX_BENCH_REHEARSE=1: development rehearsal of the N>1 control flow on a ONE-GPU box (all ranks
+    # share cuda:0, collectives over gloo).  Never used for reported numbers.
+    rehearse = os.environ.get("MIRX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- resident state ------------------------------------------------------------------
     torch.manual_seed(0)
@@ -244,7 +252,8 @@ def main():
                                    f"{args.gallery}x{args.dim} fp32 gallery (cosine), {q_local} queries/GPU/step",
                        "gallery_rows": args.gallery, "dim": args.dim, "queries_per_gpu_per_step": q_local,
                        "embed_batch": args.embed_batch, "k": args.k,
-                       "sharding": f"gallery rows / {world} GPUs + 2 all-gathers" if world > 1 else "single GPU",
+                       "sharding": (f"gallery rows / {world} GPUs + 2 all-gathers" if world > 1 else "single GPU")
+                                   + (" [REHEARSAL: ranks share one GPU, gloo]" if rehearse else ""),
                        "search_stats_last_step": stats,
                        "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
             "roofline": {"bound": "mfma", "kernel": "mirx::k_gemm<256,0,false> (bf16 MFMA distance GEMM + threshold filter)",
