@@ -53,6 +53,8 @@ SYMBOLS = {
     "mirx_index_last_timings": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "mirx_index_rank_all": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mirx_topk_merge": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "mirx_rank_metrics": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _int, _int, ctypes.c_double, _int,
+                                 ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp, _vp, _vp, _vp]),
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_bn_relu_nchw": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp]),

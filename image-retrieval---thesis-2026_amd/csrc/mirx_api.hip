@@ -628,6 +628,31 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
     return MIRX_OK;
 }
 
+int mirx_rank_metrics(const int64_t *ranks, int64_t nq, int64_t n, int64_t row_stride,
+                      const int64_t *gallery_labels, int64_t n_labels, const int64_t *query_labels,
+                      const int64_t *query_ids_or_null, int drop_self, int rel_kind, double jaccard_threshold,
+                      int ap_kind,
+                      const int32_t *kappas, int nk, double *out_ap, int64_t *out_cnt, int64_t *out_nrel,
+                      int64_t *out_maxpos, void *stream) {
+    MIRX_CHECK(nq >= 0 && n >= 0 && row_stride >= n && n_labels >= 0, "rank_metrics: bad sizes");
+    MIRX_CHECK(nq == 0 || (ranks && gallery_labels && query_labels && out_ap && out_nrel && out_maxpos),
+               "rank_metrics: null buffer");
+    MIRX_CHECK(nk >= 0 && nk <= MIRX_MAX_KAPPAS && (nk == 0 || (kappas && out_cnt)), "rank_metrics: 0 <= nk <= 8");
+    MIRX_CHECK((rel_kind == 0 || rel_kind == 1) && (ap_kind == 0 || ap_kind == 1), "rank_metrics: bad kind");
+    RankMetricsArgs a{};
+    a.ranks = ranks; a.nq = nq; a.n = n; a.row_stride = row_stride;
+    a.gallery_labels = gallery_labels; a.n_labels = n_labels; a.query_labels = query_labels;
+    a.query_ids = query_ids_or_null; a.drop_self = (drop_self && query_ids_or_null) ? 1 : 0;
+    a.jaccard_threshold = jaccard_threshold; a.nk = nk;
+    for (int j = 0; j < nk; ++j) {
+        MIRX_CHECK(kappas[j] >= 1, "rank_metrics: kappa must be >= 1");
+        a.kappas[j] = kappas[j];
+    }
+    a.out_ap = out_ap; a.out_cnt = out_cnt; a.out_nrel = out_nrel; a.out_maxpos = out_maxpos;
+    MIRX_HIP(launch_rank_metrics(a, rel_kind, ap_kind, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_l2_normalize(float *x, int64_t n, int dim, void *stream) {
     MIRX_CHECK(x && n >= 0 && dim >= 1, "l2_normalize: bad argument");
     MIRX_HIP(launch_l2_normalize(x, n, dim, reinterpret_cast<hipStream_t>(stream)));

@@ -54,6 +54,25 @@ hipError_t launch_topk_merge(const double *in_scores, const int64_t *in_ids, int
                              int64_t nq, int k, int metric, double *out_f64, float *out_val,
                              int64_t *out_ids, hipStream_t st);
 
+// ---- k_metrics.hip ----------------------------------------------------------------------
+constexpr int MIRX_MAX_KAPPAS = 8;
+struct RankMetricsArgs {
+    const int64_t *ranks;          // [nq, row_stride >= n] gallery row ids, best first
+    int64_t nq, n, row_stride;
+    const int64_t *gallery_labels; // [n_labels] class id, or multi-hot bit mask (rel_kind 1)
+    int64_t n_labels;
+    const int64_t *query_labels;   // [nq]
+    const int64_t *query_ids;      // [nq] id that is never relevant for the query, or null
+    int drop_self;                 // 1: that entry is also taken out of the list (later ranks move up)
+    double jaccard_threshold;
+    int32_t kappas[MIRX_MAX_KAPPAS];
+    int nk;
+    double *out_ap;                // [nq]
+    int64_t *out_cnt;              // [nq, nk]
+    int64_t *out_nrel, *out_maxpos;
+};
+hipError_t launch_rank_metrics(const RankMetricsArgs &a, int rel_kind, int ap_kind, hipStream_t st);
+
 // ---- k_gemm.hip -------------------------------------------------------------------------
 struct GemmArgs {
     const uint16_t *g16;   // gallery bf16 [rows, dimp]

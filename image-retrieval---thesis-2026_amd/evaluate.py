@@ -49,21 +49,23 @@ def evaluate(model, loader, device, args):
     embeds, labels = embed_loader(model, loader, device)
     metric = getattr(args, "metric", "cdist")
     ranks, sorted_scores = rank_self(embeds.float(), metric)
-    ranks_np = ranks.cpu().numpy()
     labels_np = labels.cpu().numpy()
+    k_values = [1, 5, 10, 15, 20]
+    # only the heads of the lists leave the GPU; AP / precision@k run over the full ranking on the
+    # device (mirx_rank_metrics) -- no N x N matrix crosses PCIe
+    ranks_head = ranks[:, :max(k_values)].cpu().numpy()
 
     kappas = [1, 5, 10]
-    accuracy = retrieval_accuracy(None, labels_np, topk=kappas, topk_ids=ranks_np[:, :max(kappas)])
+    accuracy = retrieval_accuracy(None, labels_np, topk=kappas, topk_ids=ranks_head[:, :max(kappas)])
     accuracy = torch.stack(accuracy).cpu().numpy()
     print(">> R@K{}: {}%".format(kappas, np.around(accuracy, 2)))
 
-    mAP, _, pr, _ = compute_map(ranks_np.T, labels_np, kappas)
+    mAP, _, pr, _ = compute_map(ranks.t(), labels_np, kappas)
     print(">> mAP: {:.2f}%".format(mAP * 100.0))
     print(">> mP@K{}: {}%".format(kappas, np.around(pr * 100.0, 2)))
 
     print("\n>> Classification Metrics (Majority Voting):")
-    k_values = [1, 5, 10, 15, 20]
-    classification_results = compute_classification_metrics(labels_np, None, k_values, ranks=ranks_np.T)
+    classification_results = compute_classification_metrics(labels_np, None, k_values, ranks=ranks_head.T)
     for k in k_values:
         m = classification_results[k]
         print(f"\n>> Top-{k} Retrieved Images:")

@@ -7,9 +7,11 @@ Mirrors (paths into /root/reference):
   compute_similarity_matrix, rank_indices, evaluate_retrieval_metrics[_from_similarity]
                                                                   fusion_eval/metrics.py:12-94
   l2_normalize, concat_fusion, weighted_sum_fusion                fusion_eval/fuse.py:11-52
-These are host-side tails (numpy); the heavy parts -- scores, top-k, full ranking -- come from
-libmirx (index.FlatIndex) and enter here as id arrays.  Functions that take a score matrix in
-the reference also accept precomputed rankings through keyword arguments.
+The heavy parts -- scores, top-k, full ranking -- come from libmirx (index.FlatIndex) and enter
+here as id arrays.  Functions that take a score matrix in the reference also accept precomputed
+rankings through keyword arguments.  When the ranking is a CUDA tensor (FlatIndex.rank_all), AP and
+precision@k are computed on the device by mirx_rank_metrics (`rank_metrics_device`) and only the
+per-query results come back; numpy inputs keep the host implementation.
 """
 from dataclasses import dataclass
 from typing import Optional
@@ -26,6 +28,75 @@ def _np(x):
     if torch is not None and isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()
     return np.asarray(x)
+
+
+def _is_cuda(x):
+    return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def rank_metrics_device(ranks, gallery_labels, query_labels, kappas=(), query_ids=None, drop_self=False,
+                        jaccard_threshold=None, standard_ap=False):
+    """One device pass over ranked lists (include/mirx.h: mirx_rank_metrics).
+
+    ranks: CUDA int64 [nq, n] (row per query, best first; a transposed view of a contiguous
+    [n, nq] tensor is copied).  labels: class ids, or multi-hot bit masks when `jaccard_threshold`
+    is given.  -> dict of CUDA tensors: ap [nq] f64 (NaN = no relevant id), cnt [nq, len(kappas)]
+    i64, nrel [nq] i64, maxpos [nq] i64."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    if ranks.dtype != torch.int64 or ranks.dim() != 2:
+        raise ValueError("rank_metrics_device: ranks must be int64 [nq, n]")
+    if ranks.stride(1) != 1 or ranks.stride(0) < ranks.shape[1]:
+        ranks = ranks.contiguous()
+    dev = ranks.device
+    nq, n = ranks.shape
+    gl = torch.as_tensor(gallery_labels).to(device=dev, dtype=torch.int64).contiguous()
+    ql = torch.as_tensor(query_labels).to(device=dev, dtype=torch.int64).contiguous()
+    if ql.numel() != nq:
+        raise ValueError("rank_metrics_device: one query label per ranked list")
+    qi = None if query_ids is None else torch.as_tensor(query_ids).to(device=dev, dtype=torch.int64).contiguous()
+    ks = [int(k) for k in kappas]
+    karr = (ctypes.c_int32 * max(1, len(ks)))(*ks)
+    ap = torch.empty(nq, dtype=torch.float64, device=dev)
+    cnt = torch.empty((nq, len(ks)), dtype=torch.int64, device=dev)
+    nrel = torch.empty(nq, dtype=torch.int64, device=dev)
+    maxpos = torch.empty(nq, dtype=torch.int64, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None  # noqa: E731
+    with torch.cuda.device(dev):
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mirx_rank_metrics(vp(ranks), nq, n, ranks.stride(0) if nq else n, vp(gl), gl.numel(), vp(ql),
+                                         vp(qi), 1 if drop_self else 0, 0 if jaccard_threshold is None else 1,
+                                         float(jaccard_threshold or 0.0), 1 if standard_ap else 0, karr, len(ks),
+                                         vp(ap), vp(cnt), vp(nrel), vp(maxpos), st), "mirx_rank_metrics")
+    return {"ap": ap, "cnt": cnt, "nrel": nrel, "maxpos": maxpos}
+
+
+def _compute_map_device(ranks, gnd, kappas):
+    gnd_t = torch.as_tensor(_np(gnd)).to(ranks.device)
+    res = rank_metrics_device(ranks.t(), gnd_t, gnd_t, kappas)
+    aps = res["ap"].cpu().numpy()
+    nq, nk = aps.shape[0], len(kappas)
+    nrel = res["nrel"].cpu().numpy().astype(np.float64)
+    maxpos = res["maxpos"].cpu().numpy().astype(np.float64)
+    cnt = res["cnt"].cpu().numpy().astype(np.float64)
+    prs = np.zeros((nq, nk))
+    for j, kap in enumerate(kappas):
+        kq = np.minimum(maxpos, float(kap))                       # test.py:139
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prs[:, j] = np.where(float(kap) <= maxpos, cnt[:, j], nrel) / kq
+    ok = ~np.isnan(aps)                                           # test.py:122-126: empty queries are skipped
+    if not ok.any():
+        return float("nan"), aps, np.full(nk, np.nan), prs
+    return float(np.sum(aps[ok]) / ok.sum()), aps, np.sum(prs[ok], axis=0) / ok.sum(), prs
+
+
+def _label_bitmasks(labels):
+    """Multi-hot [N, C <= 63] 0/1 matrix -> int64 bit masks, or None when it is not binary."""
+    lab = _np(labels)
+    if lab.ndim != 2 or lab.shape[1] > 63 or not np.isin(lab, (0, 1)).all():
+        return None
+    return (lab.astype(np.int64) << np.arange(lab.shape[1], dtype=np.int64)[None, :]).sum(axis=1)
 
 
 # ---- test.py:38-54 ---------------------------------------------------------------------------
@@ -71,6 +142,8 @@ def compute_map(ranks, gnd, kappas=[]):
     reference kept: the query itself counts as a positive (it sits at the last rank because
     its score was -inf, test.py:119,1081); precision@kappa divides by
     min(largest 1-based positive rank, kappa) (test.py:139)."""
+    if _is_cuda(ranks) and len(kappas) <= 8 and len(gnd):
+        return _compute_map_device(ranks, gnd, list(kappas))
     ranks = _np(ranks)
     gnd = _np(gnd)
     nq = len(gnd)
@@ -158,6 +231,15 @@ def compute_classification_metrics(labels, dists, k_values=[1, 5, 10, 15, 20], r
 def compute_map_multilabel(dists, labels, threshold=0.5, ranks=None):
     """Jaccard-thresholded mAP over the full ranking (query itself never relevant).
     `ranks` (optional) is [db, N] column-per-query like np.argsort(-dists, axis=0)."""
+    if _is_cuda(ranks):
+        masks = _label_bitmasks(labels)
+        if masks is not None:
+            n = masks.shape[0]
+            res = rank_metrics_device(ranks.t(), masks, masks, (), query_ids=np.arange(n),
+                                      jaccard_threshold=float(threshold), standard_ap=True)
+            aps = res["ap"].cpu().numpy()
+            aps = aps[~np.isnan(aps)]
+            return np.mean(aps) if aps.size else 0
     lab = _np(labels).astype(np.float64)
     n = lab.shape[0]
     inter = lab @ lab.T
@@ -279,11 +361,24 @@ def evaluate_retrieval_metrics_from_similarity(similarity, labels, image_paths, 
             raise ValueError("Similarity matrix must be square")
         n = similarity.shape[0]
     else:
-        ranks = _np(ranks)
         n = ranks.shape[0]
     if len(labels) != len(image_paths) or len(labels) != n:
         raise ValueError("Labels, image_paths, and similarity matrix must have matching sizes")
     ks = sorted(set(int(k) for k in k_values))
+    if _is_cuda(ranks) and len(ks) <= 8 and len(set(image_paths)) == n:
+        # unique paths: "remove the query's own path" == drop id qi from its list
+        _, lab_ids = np.unique(np.asarray(labels), return_inverse=True)
+        res = rank_metrics_device(ranks, lab_ids, lab_ids, ks, query_ids=np.arange(n), drop_self=True,
+                                  standard_ap=True)
+        aps = np.nan_to_num(res["ap"].cpu().numpy(), nan=0.0)
+        cnt = res["cnt"].cpu().numpy().astype(np.float64)
+        out = {"num_samples": float(n), "mAP": float(np.mean(aps) * 100.0)}
+        for j, k in enumerate(ks):
+            out[f"mP@{k}"] = float(np.mean(cnt[:, j] / k) * 100.0)
+            out[f"R@{k}"] = float(np.mean(cnt[:, j] > 0) * 100.0)
+        return out
+    if ranks is not None:
+        ranks = _np(ranks)
     if ranks is None:
         ranks = rank_indices(similarity)
     labels_np = np.asarray(labels)

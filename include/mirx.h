@@ -157,6 +157,29 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
                     int64_t *out_ids, void *stream);
 
 /*
+ * Metric tail over ranked lists, on the device: one pass per query over its
+ * ranking `ranks[q, 0..n)` (gallery row ids, best first; rows `row_stride` apart) gives
+ *   out_ap[q]      AP of the list: ap_kind 0 = the trapezoidal compute_ap of test.py:58-92 summed the
+ *                  way compute_map does (test.py:95-146), ap_kind 1 = mean of precision at each relevant
+ *                  rank (compute_map_multilabel test.py:941-985, fusion_eval/metrics.py:41-94);
+ *                  NaN when the list holds no relevant id (the reference's "nempty" / skipped queries);
+ *   out_cnt[q, j]  relevant ids within the first kappas[j] ranks (retrieval_accuracy test.py:38-54;
+ *                  precision@kappa test.py:137-142; mP@k / R@k of fusion_eval/metrics.py:70-86);
+ *   out_nrel[q]    relevant ids in the whole list; out_maxpos[q] largest 1-based relevant rank (0 = none).
+ * Relevance of gallery row `id` for query q: rel_kind 0 -> gallery_labels[id] == query_labels[q];
+ * rel_kind 1 -> labels are multi-hot bit masks (<= 64 classes) and
+ * |a & b| / (|a | b| + 1e-8) > jaccard_threshold (test.py:956-965).  query_ids_or_null[q] is never
+ * relevant (self-exclusion: binary_relevance[i] = 0, test.py:966).  Ids outside [0, n_labels) are
+ * not relevant.  All pointers are device pointers except kappas (host, nk <= 8).
+ */
+int mirx_rank_metrics(const int64_t *ranks, int64_t nq, int64_t n, int64_t row_stride,
+                      const int64_t *gallery_labels, int64_t n_labels, const int64_t *query_labels,
+                      const int64_t *query_ids_or_null, int drop_self, int rel_kind,
+                      double jaccard_threshold, int ap_kind, const int32_t *kappas, int nk,
+                      double *out_ap, int64_t *out_cnt, int64_t *out_nrel, int64_t *out_maxpos,
+                      void *stream);
+
+/*
  * x <- x / max(||x||_2, 1e-12) row-wise, in place.  Replaces F.normalize(x, dim=1)
  * (model.py:83,116,493,634; milvus_retrieval.py:63).  x: device [n, dim] fp32.
  */
