@@ -25,6 +25,8 @@
 //     has several MFMAs of cover before its first use;
 //   * the barrier sits in front of the LAST slice of a tile: that slice's fragments are already
 //     in registers, so its MFMAs cover the DMA issue and the first reads of tile kt+1.
+#include <cstdlib>
+
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -374,6 +376,291 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
 #undef MIRX_LDB
 }
 
+// ================================================================================================
+// The same kernel on v_mfma_f32_16x16x32_bf16 (BN = 256 only).  Same tile, schedule, LDS image and
+// epilogue contract; the wave tile (128 gallery rows x 64 queries) is 8 x 4 accumulator tiles of
+// 16 x 16 and a K-tile is two 32-deep slices.  Under load the chip holds a higher clock on this shape
+// (MI355X_MICROARCH.md, DVFS (7)): same cycles per FLOP, more FLOP/s.
+//   A fragment: lane -> gallery row (lane & 15), K chunk 4*slice + (lane >> 4)
+//   B fragment: lane -> query     (lane & 15), same K chunk
+//   accumulator register r of tile (mi, ni): gallery row 16 mi + 4 (lane >> 4) + r, query 16 ni + (lane & 15)
+// ================================================================================================
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int MODE, bool L2>
+__global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
+    constexpr int BN = 256;
+    constexpr int WARPS_N = 4, WARPS_M = 2;
+    constexpr int WM_ROWS = BM / WARPS_M;        // 128 gallery rows per wave
+    constexpr int M_REP = WM_ROWS / 16;          // 8
+    constexpr int N_REP = 4;                     // 64 queries per wave
+    constexpr int B_TILE_BYTES = BN * ROW_BYTES;
+    constexpr int LDS_B0 = 2 * A_TILE_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+    const int nk = A.dimp / BK;                   // even
+    const int ld_bytes = A.dimp * 2;
+
+    Plan plan;
+    plan.ngt = (A.n_rows + BM - 1) / BM;
+    plan.nqt = (int)(A.nq_pad / BN);
+    plan.nph = A.nph;
+    plan.grid = gridDim.x;
+    const int u = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (u >= plan.units()) return;
+    int qt, ph;
+    plan.unit(u, qt, ph);
+    const int64_t q_row0 = (int64_t)qt * BN;
+    int *lcnt = reinterpret_cast<int *>(smem + LDS_B0 + 2 * B_TILE_BYTES);   // [BN][WARPS_M] region fill counts
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) lcnt[i] = 0;
+    }
+
+    const int prow = wave * 8 + (lane >> 3);
+    const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+    const int rs = (int)A.row_stride;
+    const int voff_a = prow * rs * ld_bytes + pchunk * 16;
+    const int voff_b = prow * ld_bytes + pchunk * 16;
+    const int pstride_a = 64 * rs * ld_bytes;
+    const int pstride_b = 64 * ld_bytes;
+    auto make_rsrc_a = [&](int64_t gt_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(A.g16 + gt_ * BM * A.row_stride * A.dimp), 0,
+                                                 BM * rs * ld_bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(A.q16 + q_row0 * A.dimp), 0, BN * ld_bytes, 0x00020000);
+
+    // (row r, chunk c) lives at r*128 + ((c ^ ((r>>1)&7)) << 4); r = 16*tile + (lane & 15),
+    // c = 4*slice + (lane >> 4)  ->  (((lane >> 4) ^ sw) << 4) XOR (slice << 6)
+    const int sw = ((lane & 15) >> 1) & 7;
+    const int frag_lo = (((lane >> 4) ^ sw) << 4);
+    const int a_base = (wm * WM_ROWS + (lane & 15)) * ROW_BYTES + frag_lo;
+    const int b_base = LDS_B0 + (wn * 64 + (lane & 15)) * ROW_BYTES + frag_lo;
+    // fragment byte address of (buffer, slice): base ^ (buffer << 15) ^ (slice << 6); the loop keeps the
+    // CURRENT buffer's base in acur / bcur and flips bit 15 once per K-tile
+    int acur = a_base, bcur = b_base;
+
+    // thresholds of this workgroup's 256 queries: LDS, read back per gallery tile by the epilogue
+    float *ltau = reinterpret_cast<float *>(lcnt + BN * WARPS_M);
+    if (MODE == 0 && threadIdx.x < BN) ltau[threadIdx.x] = A.tau[q_row0 + threadIdx.x];
+    const int region = ph * WARPS_M + wm;
+
+    f32x4 acc[M_REP][N_REP];
+
+    auto epilogue = [&](int64_t gt_) {
+        // Everything the epilogue needs besides tau[] is re-derived here from an opaque copy of the lane
+        // id, so that none of it (64-bit columns, pointers, ballot masks) is hoisted into the K loop's
+        // live registers -- the loop has none to spare.
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int quad = el >> 4, col = el & 15;
+        const int64_t tile_row0 = gt_ * BM + wm * WM_ROWS;
+        float tau[N_REP];
+#pragma unroll
+        for (int ni = 0; ni < N_REP; ++ni) tau[ni] = MODE == 0 ? ltau[wn * 64 + ni * 16 + col] : 0.0f;
+        if (L2) {
+#pragma unroll
+            for (int m0 = 0; m0 < M_REP; m0 += 2) {
+                float b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    b[j] = A.gbias[(tile_row0 + (m0 + (j >> 2)) * 16 + 4 * quad + (j & 3)) * A.row_stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < N_REP; ++ni) acc[m0 + (j >> 2)][ni][j & 3] += b[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < N_REP; ++ni) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
+            if (MODE == 1) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (quad == 0)
+                    A.groupmax[(q_row0 + wn * 64 + ni * 16 + col) * A.ngroups + gt_ * WARPS_M + wm] = mx;
+            } else if (__any(mx > tau[ni])) {
+                // rare path, see k_gemm.  The four lanes that share a query (lane & 15) claim consecutive
+                // slots in one step: rank among the passing lanes of the same query, by ballot.
+                const int64_t qc = q_row0 + wn * 64 + ni * 16 + col;
+                const int cidx = (wn * 64 + ni * 16 + col) * WARPS_M + wm;
+                Cand *dst = A.cand + (qc * A.regions + region) * A.slots;
+                const unsigned long long mine = 0x0001000100010001ull << col;
+                const unsigned long long below = mine & ((1ull << el) - 1ull);
+#pragma unroll
+                for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[mi][ni][r];
+                        const int64_t grow = (tile_row0 + mi * 16 + 4 * quad + r) * A.row_stride;
+                        const bool pass = v > tau[ni] && grow < A.n_rows;
+                        const unsigned long long pm = __ballot(pass);
+                        if (pm != 0) {
+                            const int base = lcnt[cidx];
+                            if (pass) {
+                                const int c = base + __popcll(pm & below);
+                                Cand cd;
+                                cd.s = v;
+                                cd.row = (int32_t)grow;
+                                if (c < A.slots) {
+                                    dst[c] = cd;
+                                } else {
+                                    const int p = atomicAdd(&A.ovf_cnt[qc], 1);
+                                    if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
+                                }
+                                if ((pm & mine & ~((2ull << el) - 1ull)) == 0)        // last passing lane of this query
+                                    lcnt[cidx] = base + __popcll(pm & mine);
+                            }
+                        }
+                    }
+            }
+        }
+    };
+
+    // Fragments: 8 A + 4 B, single-buffered and rolling (48 VGPRs).  A 32-deep slice runs as two halves:
+    //   H1: all row tiles x query tiles 0,1; meanwhile B fragments 2,3 of THIS slice are read;
+    //   H2: all row tiles x query tiles 2,3; after row tile mi's pair its A fragment is re-read for the
+    //       NEXT slice, and B fragments 0,1 of the next slice are read.
+    // Every ds_read has >= 12 MFMAs (192 cycles) between issue and first use.
+    bf16x8 fa[M_REP], fb[N_REP];
+
+    static_assert(A_TILE_BYTES == 32768 && BN * ROW_BYTES == 32768, "buffer toggle assumes 32 KiB tiles");
+    // OTHER = 0: the current buffer, 1: the other one
+#define MIRX_LDA(S, OTHER, MI) (*reinterpret_cast<const bf16x8 *>(smem + (acur ^ ((OTHER) << 15) ^ ((S) << 6)) + (MI) * 16 * ROW_BYTES))
+#define MIRX_LDB(S, OTHER, NI) (*reinterpret_cast<const bf16x8 *>(smem + (bcur ^ ((OTHER) << 15) ^ ((S) << 6)) + (NI) * 16 * ROW_BYTES))
+#define MIRX_MFMA2(MI, N0)                                                                             \
+    acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], acc[MI][N0], 0, 0, 0);       \
+    acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], acc[MI][N0 + 1], 0, 0, 0);
+#define MIRX_H1_HEAD(OTHER, S)                            \
+    MIRX_MFMA2(0, 0)                                      \
+    fb[2] = MIRX_LDB(S, OTHER, 2);                        \
+    fb[3] = MIRX_LDB(S, OTHER, 3);                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#define MIRX_H1(OTHER, S)                                 \
+    MIRX_H1_HEAD(OTHER, S)                                \
+    MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0) \
+    MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
+    // the A fragment of row tile MI is re-read one row tile late (after the NEXT pair of MFMAs), so the
+    // ds_read never overwrites a register an MFMA issued just before is still reading
+#define MIRX_H2_ROW(MI, NCUR, NS)                         \
+    MIRX_MFMA2(MI, 2)                                     \
+    fa[MI - 1] = MIRX_LDA(NS, NCUR, MI - 1);              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define MIRX_H2(NCUR, NS)                                 \
+    MIRX_MFMA2(0, 2)                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    MIRX_H2_ROW(1, NCUR, NS)                              \
+    MIRX_H2_ROW(2, NCUR, NS)                              \
+    fb[0] = MIRX_LDB(NS, NCUR, 0);                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+    MIRX_H2_ROW(3, NCUR, NS)                              \
+    MIRX_H2_ROW(4, NCUR, NS)                              \
+    fb[1] = MIRX_LDB(NS, NCUR, 1);                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+    MIRX_H2_ROW(5, NCUR, NS)                              \
+    MIRX_H2_ROW(6, NCUR, NS)                              \
+    MIRX_H2_ROW(7, NCUR, NS)                              \
+    fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    // one K-tile (held in buffer `cur`): slice 0 = H1 H2, slice 1 = H1 | barrier + DMA into `cur` | H2
+    // (which reads the first fragments of the next K-tile from the other buffer).  Branch-free around the
+    // MFMAs (see k_gemm).
+#define MIRX_KTILE(KT)                                                                             \
+    MIRX_H1(0, 0)                                                                                  \
+    MIRX_H2(0, 1)                                                                                  \
+    MIRX_H1_HEAD(0, 1)                                                                             \
+    MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0)                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
+    MIRX_KBARRIER(); /* last reads of `cur` returned; the other buffer's DMA (mine) landed */      \
+    if ((KT) + 2 < nk) {                                                                           \
+        stage_tile<BM>(smem + cur * A_TILE_BYTES, rsrc_a, voff_a, ((KT) + 2) * ROW_BYTES, pstride_a, wave); \
+        stage_tile<BN>(smem + LDS_B0 + cur * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2) * ROW_BYTES, pstride_b, wave); \
+    } else if (have_next) {                                                                        \
+        stage_tile<BM>(smem + cur * A_TILE_BYTES, rsrc_a_nx, voff_a, ((KT) + 2 - nk) * ROW_BYTES, pstride_a, wave); \
+        stage_tile<BN>(smem + LDS_B0 + cur * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2 - nk) * ROW_BYTES, pstride_b, wave); \
+    }                                                                                              \
+    MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                             \
+    MIRX_H2(1, 0)                                                                                  \
+    acur ^= 32768;                                                                                 \
+    bcur ^= 32768;                                                                                 \
+    cur ^= 1;
+
+    int64_t gt = ph;
+    __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc_a(gt);
+
+    stage_tile<BM>(smem, rsrc_a, voff_a, 0, pstride_a, wave);
+    stage_tile<BN>(smem + LDS_B0, rsrc_b, voff_b, 0, pstride_b, wave);
+    __syncthreads();
+    stage_tile<BM>(smem + A_TILE_BYTES, rsrc_a, voff_a, ROW_BYTES, pstride_a, wave);
+    stage_tile<BN>(smem + LDS_B0 + B_TILE_BYTES, rsrc_b, voff_b, ROW_BYTES, pstride_b, wave);
+#pragma unroll
+    for (int mi = 0; mi < M_REP; ++mi) fa[mi] = MIRX_LDA(0, 0, mi);
+#pragma unroll
+    for (int ni = 0; ni < N_REP; ++ni) fb[ni] = MIRX_LDB(0, 0, ni);
+    int cur = 0;                                       // nk is even: every gallery tile starts in buffer 0
+
+    for (;;) {
+        const int64_t gt_nx = gt + plan.nph;
+        const bool have_next = gt_nx < plan.ngt;
+        const __amdgpu_buffer_rsrc_t rsrc_a_nx = make_rsrc_a(have_next ? gt_nx : gt);
+
+#pragma unroll
+        for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < N_REP; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0f;
+
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            MIRX_KTILE(kt)
+        }
+
+        epilogue(gt);
+        if (!have_next) break;
+        gt = gt_nx;
+        rsrc_a = rsrc_a_nx;
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) {
+            const int c = lcnt[i];
+            if (c > 0) A.region_cnt[(q_row0 + i / WARPS_M) * A.regions + ph * WARPS_M + (i % WARPS_M)] = c;
+        }
+    }
+#undef MIRX_KTILE
+#undef MIRX_H1
+#undef MIRX_H1_HEAD
+#undef MIRX_H2
+#undef MIRX_H2_ROW
+#undef MIRX_MFMA2
+#undef MIRX_LDA
+#undef MIRX_LDB
+}
+
+// MIRX_GEMM_MFMA=32 selects the 32x32x16 kernel for the 256-query tile (development A/B switch)
+bool use_mfma16() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MIRX_GEMM_MFMA");
+        v = (e && e[0] == '3') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 int device_cus() {
     static int ncu = 0;
     if (ncu == 0) {
@@ -388,7 +675,7 @@ template <int BN, int MODE>
 hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {
     GemmArgs a = a0;
     const size_t lds = 2 * (size_t)A_TILE_BYTES + 2 * (size_t)BN * ROW_BYTES +
-                       (MODE == 0 ? (size_t)BN * (8 / (BN / 64)) * sizeof(int) : 0);
+                       (MODE == 0 ? (size_t)BN * (8 / (BN / 64)) * sizeof(int) + (size_t)BN * sizeof(float) : 0);
     const Plan plan = make_plan(a.n_rows, a.nq_pad, BN, device_cus() / 8 * 8);
     if (plan.ngt <= 0 || plan.nqt <= 0) return hipSuccess;
     a.nph = plan.nph;
@@ -397,6 +684,22 @@ hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {
     // a tile's byte span must fit the 32-bit buffer offsets
     if ((int64_t)BM * a.row_stride * a.dimp * 2 > 0x7FFFFFFF) return hipErrorInvalidValue;
     hipError_t e;
+    if constexpr (BN == 256) {
+        if (use_mfma16()) {
+            if (a.gbias) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm16<MODE, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((k_gemm16<MODE, true>), dim3((unsigned)plan.grid), dim3(512), lds, st, a);
+            } else {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm16<MODE, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((k_gemm16<MODE, false>), dim3((unsigned)plan.grid), dim3(512), lds, st, a);
+            }
+            return hipGetLastError();
+        }
+    }
     if (a.gbias) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm<BN, MODE, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
