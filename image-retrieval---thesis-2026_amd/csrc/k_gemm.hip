@@ -323,6 +323,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
     }                                                                                              \
     MIRX_SLICE(fb1, fb0, (CUR) ^ 1, 0)
 
+#ifdef MIRX_EXP_PRIO32
+    if (wave >= 4) __builtin_amdgcn_s_setprio(3);
+#endif
     int64_t gt = ph;
     __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc_a(gt);
 
@@ -540,17 +543,45 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #define MIRX_MFMA2(MI, N0)                                                                             \
     acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], acc[MI][N0], 0, 0, 0);       \
     acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], acc[MI][N0 + 1], 0, 0, 0);
+    // ---- LDS-DMA of the K-tile after next, one 1-KiB piece at a time --------------------------------
+    // A wave's issue stalls for 60-180 cycles on every `buffer_load ... lds` piece, and right after the
+    // workgroup barrier all eight waves would stall together while the MFMA pipes drain.  So the eight
+    // pieces a wave owns per K-tile (4 of the gallery tile, 4 of the query tile) are spread over the ~30
+    // MFMAs that follow the barrier, one piece per four MFMAs, and the two waves that share a SIMD
+    // (wave w and w + 4) take alternate slots: while one stalls on a piece the other feeds the matrix
+    // pipe.  A slot is a wave-uniform branch, which also pins it between the MFMA pairs around it.
+    // The source of the K-tile in flight (this gallery tile, or the next one for the last two K-tiles)
+    // is chosen at the barrier without a branch; past the very last K-tile the pieces re-read the
+    // current tile into a buffer nobody consumes.
+    const int grp = wave >> 2;
+    __amdgpu_buffer_rsrc_t dma_rsrc;               // gallery-tile descriptor of the K-tile in flight
+    int dma_koff;                                  // its K byte offset
+    char *dma_a, *dma_b;                           // this wave's first piece slot of the destination buffers
+#define MIRX_DMA_AT_BARRIER(KT)                                                     \
+    {                                                                               \
+        const int k2 = (KT) + 2;                                                    \
+        const bool wrap = k2 >= nk;                                                 \
+        dma_rsrc = wrap ? rsrc_a_nx : rsrc_a;                                       \
+        dma_koff = (wrap ? k2 - nk : k2) * ROW_BYTES;                               \
+        dma_a = smem + cur * A_TILE_BYTES + wave * 1024;                            \
+        dma_b = smem + LDS_B0 + cur * B_TILE_BYTES + wave * 1024;                   \
+    }
+#define MIRX_SLOT_A(G, P)                                                           \
+    if (grp == (G))                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, LDS_PTR(dma_a + (P) * 8192), 16, voff_a, \
+                                                 dma_koff + (P) * pstride_a, 0, 0);
+#define MIRX_SLOT_B(G, P)                                                           \
+    if (grp == (G))                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(dma_b + (P) * 8192), 16, voff_b, \
+                                                 dma_koff + (P) * pstride_b, 0, 0);
+
+    // H1 of a slice: query tiles 0,1 of every row tile; B fragments 2,3 of the same slice are read early
 #define MIRX_H1_HEAD(OTHER, S)                            \
     MIRX_MFMA2(0, 0)                                      \
     fb[2] = MIRX_LDB(S, OTHER, 2);                        \
     fb[3] = MIRX_LDB(S, OTHER, 3);                        \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#define MIRX_H1(OTHER, S)                                 \
-    MIRX_H1_HEAD(OTHER, S)                                \
-    MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0) \
-    MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 14, 0);
     // the A fragment of row tile MI is re-read one row tile late (after the NEXT pair of MFMAs), so the
     // ds_read never overwrites a register an MFMA issued just before is still reading
 #define MIRX_H2_ROW(MI, NCUR, NS)                         \
@@ -558,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     fa[MI - 1] = MIRX_LDA(NS, NCUR, MI - 1);              \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    // H2 of a slice (query tiles 2,3) without DMA slots
 #define MIRX_H2(NCUR, NS)                                 \
     MIRX_MFMA2(0, 2)                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
@@ -574,26 +606,57 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     MIRX_H2_ROW(7, NCUR, NS)                              \
     fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    // one K-tile (held in buffer `cur`): slice 0 = H1 H2, slice 1 = H1 | barrier + DMA into `cur` | H2
-    // (which reads the first fragments of the next K-tile from the other buffer).  Branch-free around the
-    // MFMAs (see k_gemm).
+    // H2 of a K-tile's last slice: reads the next K-tile's first fragments and carries eight DMA slots
+#define MIRX_H2_DMA(NCUR, NS)                             \
+    MIRX_MFMA2(0, 2)                                      \
+    MIRX_SLOT_A(0, 2)                                     \
+    MIRX_H2_ROW(1, NCUR, NS)                              \
+    MIRX_SLOT_A(1, 2)                                     \
+    MIRX_H2_ROW(2, NCUR, NS)                              \
+    fb[0] = MIRX_LDB(NS, NCUR, 0);                        \
+    MIRX_SLOT_A(0, 3)                                     \
+    MIRX_H2_ROW(3, NCUR, NS)                              \
+    MIRX_SLOT_A(1, 3)                                     \
+    MIRX_H2_ROW(4, NCUR, NS)                              \
+    fb[1] = MIRX_LDB(NS, NCUR, 1);                        \
+    MIRX_SLOT_B(0, 0)                                     \
+    MIRX_H2_ROW(5, NCUR, NS)                              \
+    MIRX_SLOT_B(1, 0)                                     \
+    MIRX_H2_ROW(6, NCUR, NS)                              \
+    MIRX_SLOT_B(0, 1)                                     \
+    MIRX_H2_ROW(7, NCUR, NS)                              \
+    fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
+    MIRX_SLOT_B(1, 1)
+    // one K-tile (held in buffer `cur`):
+    //   slice 0: H1 (with the last four DMA slots of the K-tile in flight), H2
+    //   slice 1: H1 | barrier: buffer `cur` is free, the other buffer's DMA has landed | H2 with DMA slots,
+    //            reading the first fragments of the next K-tile from the other buffer.
+    // No branch encloses an MFMA (see k_gemm).
 #define MIRX_KTILE(KT)                                                                             \
-    MIRX_H1(0, 0)                                                                                  \
+    MIRX_H1_HEAD(0, 0)                                                                             \
+    MIRX_SLOT_B(0, 2)                                                                              \
+    MIRX_MFMA2(1, 0)                                                                               \
+    MIRX_SLOT_B(1, 2)                                                                              \
+    MIRX_MFMA2(2, 0)                                                                               \
+    MIRX_SLOT_B(0, 3)                                                                              \
+    MIRX_MFMA2(3, 0)                                                                               \
+    MIRX_SLOT_B(1, 3)                                                                              \
+    MIRX_MFMA2(4, 0) MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
     MIRX_H2(0, 1)                                                                                  \
     MIRX_H1_HEAD(0, 1)                                                                             \
     MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0)                            \
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
     MIRX_KBARRIER(); /* last reads of `cur` returned; the other buffer's DMA (mine) landed */      \
-    if ((KT) + 2 < nk) {                                                                           \
-        stage_tile<BM>(smem + cur * A_TILE_BYTES, rsrc_a, voff_a, ((KT) + 2) * ROW_BYTES, pstride_a, wave); \
-        stage_tile<BN>(smem + LDS_B0 + cur * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2) * ROW_BYTES, pstride_b, wave); \
-    } else if (have_next) {                                                                        \
-        stage_tile<BM>(smem + cur * A_TILE_BYTES, rsrc_a_nx, voff_a, ((KT) + 2 - nk) * ROW_BYTES, pstride_a, wave); \
-        stage_tile<BN>(smem + LDS_B0 + cur * B_TILE_BYTES, rsrc_b, voff_b, ((KT) + 2 - nk) * ROW_BYTES, pstride_b, wave); \
-    }                                                                                              \
-    MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                             \
-    MIRX_H2(1, 0)                                                                                  \
+    MIRX_DMA_AT_BARRIER(KT)                                                                        \
+    MIRX_SLOT_A(0, 0)                                                                              \
+    MIRX_MFMA2(5, 0)                                                                               \
+    MIRX_SLOT_A(1, 0)                                                                              \
+    MIRX_MFMA2(6, 0)                                                                               \
+    MIRX_SLOT_A(0, 1)                                                                              \
+    MIRX_MFMA2(7, 0)                                                                               \
+    MIRX_SLOT_A(1, 1)                                                                              \
+    MIRX_H2_DMA(1, 0)                                                                              \
     acur ^= 32768;                                                                                 \
     bcur ^= 32768;                                                                                 \
     cur ^= 1;
@@ -611,6 +674,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #pragma unroll
     for (int ni = 0; ni < N_REP; ++ni) fb[ni] = MIRX_LDB(0, 0, ni);
     int cur = 0;                                       // nk is even: every gallery tile starts in buffer 0
+    // "K-tile in flight" before the first barrier: K-tile 1 -> buffer 1, which the prologue above has
+    // already requested in full; the first iteration's four late slots fetch the same bytes again
+    dma_rsrc = rsrc_a;
+    dma_koff = ROW_BYTES;
+    dma_a = smem + A_TILE_BYTES + wave * 1024;
+    dma_b = smem + LDS_B0 + B_TILE_BYTES + wave * 1024;
+    // Waves 4-7 are the younger SIMD partners and lose every issue arbitration against waves 0-3, which
+    // then wait for them at each barrier: a static priority for the younger half evens the two out
+    // (bench: 5.75 -> 5.54 ms per 4096-query launch).
+    if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 
     for (;;) {
         const int64_t gt_nx = gt + plan.nph;
@@ -642,9 +715,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         }
     }
 #undef MIRX_KTILE
-#undef MIRX_H1
 #undef MIRX_H1_HEAD
 #undef MIRX_H2
+#undef MIRX_H2_DMA
+#undef MIRX_SLOT_A
+#undef MIRX_SLOT_B
+#undef MIRX_DMA_AT_BARRIER
 #undef MIRX_H2_ROW
 #undef MIRX_MFMA2
 #undef MIRX_LDA
