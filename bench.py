@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (all GPUs)")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--queries", type=int, default=4096, help="queries (images) per GPU per step")
-    ap.add_argument("--embed-batch", type=int, default=1024)
+    ap.add_argument("--embed-batch", type=int, default=2048)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,7 +91,7 @@ def gemm_traffic_from_profile(args, world, q_local):
     fetch, write = [], []
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if "k_gemm<256, 0" in r["Kernel_Name"]:
+            if "k_gemm16<0, false>" in r["Kernel_Name"]:
                 if r["Counter_Name"] == "FETCH_SIZE":
                     fetch.append(float(r["Counter_Value"]))
                 elif r["Counter_Name"] == "WRITE_SIZE":
@@ -256,7 +256,7 @@ def main():
                                    + (" [REHEARSAL: ranks share one GPU, gloo]" if rehearse else ""),
                        "search_stats_last_step": stats,
                        "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
-            "roofline": {"bound": "mfma", "kernel": "mirx::k_gemm<256,0,false> (bf16 MFMA distance GEMM + threshold filter)",
+            "roofline": {"bound": "mfma", "kernel": "mirx::k_gemm16<0,false> (bf16 16x16x32 MFMA distance GEMM + threshold filter)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                          "flop_per_launch": flop, "avg_launch_ms": avg_gemm_ms},
