@@ -228,6 +228,10 @@ hipError_t launch_select_tau(const float *groupmax, int ngroups, int64_t nq, int
     if (nq_pad <= 0) return hipSuccess;
     int m = 1;
     while (m < ngroups) m <<= 1;
+    if (m > 16384) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_select_tau),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select_tau, dim3((unsigned)nq_pad), dim3(256), (size_t)m * sizeof(float), st,
                        groupmax, ngroups, nq, rank_j, tau);
     return hipGetLastError();

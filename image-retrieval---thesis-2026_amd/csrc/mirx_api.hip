@@ -294,12 +294,16 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
             MIRX_HIP(hipMemcpyAsync(ix->tau.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, st));
             MIRX_HIP(hipStreamSynchronize(st));
         } else {
-            // sample = every `stride`-th row, about size/32 rows, a multiple of the 256-row tile
-            int64_t ms = round_up(std::max<int64_t>(ix->size / 32, 4096), ROW_ALIGN);
-            ms = std::min<int64_t>(ms, 65536);
-            const int64_t stride = std::max<int64_t>(ix->size / ms, 1);
+            // sample = every `stride`-th row, about size/32 rows, a multiple of the 256-row tile; at most
+            // 16384 group maxima per query (the selection sorts them in LDS).  The threshold is the j-th
+            // largest sampled group maximum with j ~ 256 / stride, i.e. about 256 expected candidates per
+            // query whatever the gallery size (j = sample_rank = 8 at the usual stride of 32).
             const int gpt = gemm_groups_per_tile(bn);
+            int64_t ms = round_up(std::max<int64_t>(ix->size / 32, 4096), ROW_ALIGN);
+            ms = std::min<int64_t>(ms, (int64_t)(16384 / gpt) * ROW_ALIGN);
+            const int64_t stride = std::max<int64_t>(ix->size / ms, 1);
             const int ngroups = (int)(ms / ROW_ALIGN) * gpt;
+            const int rank_j = (int)std::max<int64_t>(1, std::min<int64_t>(ix->sample_rank, (32 * (int64_t)ix->sample_rank) / stride));
             MIRX_HIP(ix->groupmax.ensure((size_t)nb_pad * ngroups * sizeof(float)));
             GemmArgs gs = ga;
             gs.n_rows = ms;
@@ -308,8 +312,7 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
             gs.ngroups = ngroups;
             StageTimer t(ix, st, MIRX_STAGE_SAMPLE);
             MIRX_HIP(launch_gemm_groupmax(gs, bn, st));
-            MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, ix->sample_rank,
-                                       ix->tau.as<float>(), st));
+            MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, rank_j, ix->tau.as<float>(), st));
         }
         MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * regions * sizeof(int), st));
         MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nb_pad * sizeof(int), st));

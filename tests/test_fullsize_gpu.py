@@ -97,3 +97,43 @@ def test_oracle_on_a_few_queries_at_full_size(big):
     o_s, o_i = OS.topk(qs.cpu().numpy(), host, K)
     np.testing.assert_array_equal(i.cpu().numpy(), o_i)
     np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+
+
+@pytest.mark.gpu
+def test_eight_million_rows_planted_neighbours():
+    """8M x 1024 rows (48 GB resident: byte offsets past 2^32 everywhere): planted near-duplicates of 256
+    gallery rows must come back as (itself, its twin) with fp64-exact scores, from the MFMA tier."""
+    from mirx.index import FlatIndex
+    dev = torch.device("cuda:0")
+    n, d, nq = 8_000_000, 1024, 256
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 70 * 2**30:
+        pytest.skip("needs ~50 GB of free HBM")
+    g = torch.Generator(device=dev).manual_seed(99)
+    ix = FlatIndex(d, "COSINE", 0)
+    ix.reserve(n)
+    qrows = torch.arange(nq, device=dev) * 31_013 + 17            # spread over the whole id range (< 8M)
+    twins = n - 1 - torch.arange(nq, device=dev) * 7              # their near-duplicates live at the far end
+    keep = {}
+    chunk = 1 << 19
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        x = torch.nn.functional.normalize(torch.randn(m, d, generator=g, device=dev), dim=1)
+        for j, (a, b) in enumerate(zip(qrows.tolist(), twins.tolist())):
+            if s <= a < s + m:
+                keep[j] = x[a - s].clone()
+        for j, b in enumerate(twins.tolist()):                     # twins are in the last chunk(s): after their originals
+            if s <= b < s + m and j in keep:
+                noise = torch.randn(d, generator=g, device=dev)
+                x[b - s] = torch.nn.functional.normalize(keep[j] + 0.05 * noise / noise.norm(), dim=0)
+        ix.add(x)
+    assert len(ix) == n and len(keep) == nq
+    q = torch.stack([keep[j] for j in range(nq)])
+    sc, ids = ix.search(q, 2, return_f64=True)
+    st = ix.last_stats()
+    assert st["tier1_answered"] == nq and st["exact_answered"] == 0
+    assert torch.equal(ids[:, 0], qrows) and torch.equal(ids[:, 1], twins)
+    rows, _ = ix.rows(int(twins[5]), 1)
+    want = float((q[5].double() * rows[0].double()).sum())
+    assert abs(float(sc[5, 1]) - want) < 1e-12
+    assert torch.all(sc[:, 0] > 0.999999) and torch.all(sc[:, 1] > 0.99)
