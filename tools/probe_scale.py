@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Tier-1 statistics of a random N x 1024 gallery for one gallery size (development tool):
+python tools/probe_scale.py 24000000"""
 import sys, torch
 sys.path.insert(0, '.')
 from mirx.index import FlatIndex
