@@ -497,7 +497,18 @@ class _VitAttention(nn.Module):
 
     def forward(self, x):
         b, n, c = x.shape
-        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+        dh = c // self.num_heads
+        qkv = self.qkv(x)                                                # [b, n, 3, heads, dh] packed
+        if x.is_cuda and dh == 64 and qkv.dtype == torch.float32 and not torch.is_grad_enabled():
+            # MI355X inference path: fp32 MFMA flash attention straight on the packed projection,
+            # output already [b, n, heads * dh] (include/mirx.h: mirx_attention_qkv_f32)
+            qkv = qkv.contiguous()
+            a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, self.num_heads, dh, float(dh) ** -0.5,
+                                                              _ptr(a), _stream(x.device)), "mirx_attention_qkv_f32")
+            return self.proj(a)
+        qkv = qkv.reshape(b, n, 3, self.num_heads, dh).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])      # softmax(q k^T / sqrt(d)) v
         return self.proj(a.transpose(1, 2).reshape(b, n, c))
 

@@ -157,6 +157,16 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
                     int64_t *out_ids, void *stream);
 
 /*
+ * Multi-head self-attention of the ViT backbones, fp32: out = softmax(q k^T * scale) v per (image,
+ * head), scores never materialised.  Replaces the attention of timm's `vit_base_patch14_dinov2`
+ * blocks (model.py:459-463; nih_multilabel_retrieval.py:175-221).  qkv: device [batch, n_tokens, 3,
+ * heads, head_dim] fp32, exactly the output of the block's qkv Linear; out: device [batch, n_tokens,
+ * heads, head_dim] fp32 (= [batch, n_tokens, C], no head transpose).  head_dim must be 64.
+ */
+int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
+                           float scale, float *out, void *stream);
+
+/*
  * Metric tail over ranked lists, on the device: one pass per query over its
  * ranking `ranks[q, 0..n)` (gallery row ids, best first; rows `row_stride` apart) gives
  *   out_ap[q]      AP of the list: ap_kind 0 = the trapezoidal compute_ap of test.py:58-92 summed the
