@@ -540,9 +540,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // OTHER = 0: the current buffer, 1: the other one
 #define MIRX_LDA(S, OTHER, MI) (*reinterpret_cast<const bf16x8 *>(smem + (acur ^ ((OTHER) << 15) ^ ((S) << 6)) + (MI) * 16 * ROW_BYTES))
 #define MIRX_LDB(S, OTHER, NI) (*reinterpret_cast<const bf16x8 *>(smem + (bcur ^ ((OTHER) << 15) ^ ((S) << 6)) + (NI) * 16 * ROW_BYTES))
-#define MIRX_MFMA2(MI, N0)                                                                             \
-    acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], acc[MI][N0], 0, 0, 0);       \
-    acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], acc[MI][N0 + 1], 0, 0, 0);
+    // Z = 1: the first slice of a gallery tile starts its 32 accumulator tiles from the constant 0 (no
+    // 128 v_mov per tile)
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#define MIRX_MFMA2Z(MI, N0, Z)                                                                         \
+    acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], (Z) ? zero4 : acc[MI][N0], 0, 0, 0); \
+    acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], (Z) ? zero4 : acc[MI][N0 + 1], 0, 0, 0);
+#define MIRX_MFMA2(MI, N0) MIRX_MFMA2Z(MI, N0, 0)
     // ---- LDS-DMA of the K-tile after next, one 1-KiB piece at a time --------------------------------
     // A wave's issue stalls for 60-180 cycles on every `buffer_load ... lds` piece, and right after the
     // workgroup barrier all eight waves would stall together while the MFMA pipes drain.  So the eight
@@ -576,34 +580,35 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                                                  dma_koff + (P) * pstride_b, 0, 0);
 
     // H1 of a slice: query tiles 0,1 of every row tile; B fragments 2,3 of the same slice are read early
-#define MIRX_H1_HEAD(OTHER, S)                            \
-    MIRX_MFMA2(0, 0)                                      \
+#define MIRX_H1_HEAD(OTHER, S, Z)                         \
+    MIRX_MFMA2Z(0, 0, Z)                                  \
     fb[2] = MIRX_LDB(S, OTHER, 2);                        \
     fb[3] = MIRX_LDB(S, OTHER, 3);                        \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     // the A fragment of row tile MI is re-read one row tile late (after the NEXT pair of MFMAs), so the
     // ds_read never overwrites a register an MFMA issued just before is still reading
-#define MIRX_H2_ROW(MI, NCUR, NS)                         \
-    MIRX_MFMA2(MI, 2)                                     \
+#define MIRX_H2_ROWZ(MI, NCUR, NS, Z)                     \
+    MIRX_MFMA2Z(MI, 2, Z)                                 \
     fa[MI - 1] = MIRX_LDA(NS, NCUR, MI - 1);              \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#define MIRX_H2_ROW(MI, NCUR, NS) MIRX_H2_ROWZ(MI, NCUR, NS, 0)
     // H2 of a slice (query tiles 2,3) without DMA slots
-#define MIRX_H2(NCUR, NS)                                 \
-    MIRX_MFMA2(0, 2)                                      \
+#define MIRX_H2(NCUR, NS, Z)                              \
+    MIRX_MFMA2Z(0, 2, Z)                                  \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
-    MIRX_H2_ROW(1, NCUR, NS)                              \
-    MIRX_H2_ROW(2, NCUR, NS)                              \
+    MIRX_H2_ROWZ(1, NCUR, NS, Z)                          \
+    MIRX_H2_ROWZ(2, NCUR, NS, Z)                          \
     fb[0] = MIRX_LDB(NS, NCUR, 0);                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
-    MIRX_H2_ROW(3, NCUR, NS)                              \
-    MIRX_H2_ROW(4, NCUR, NS)                              \
+    MIRX_H2_ROWZ(3, NCUR, NS, Z)                          \
+    MIRX_H2_ROWZ(4, NCUR, NS, Z)                          \
     fb[1] = MIRX_LDB(NS, NCUR, 1);                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
-    MIRX_H2_ROW(5, NCUR, NS)                              \
-    MIRX_H2_ROW(6, NCUR, NS)                              \
-    MIRX_H2_ROW(7, NCUR, NS)                              \
+    MIRX_H2_ROWZ(5, NCUR, NS, Z)                          \
+    MIRX_H2_ROWZ(6, NCUR, NS, Z)                          \
+    MIRX_H2_ROWZ(7, NCUR, NS, Z)                          \
     fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     // H2 of a K-tile's last slice: reads the next K-tile's first fragments and carries eight DMA slots
@@ -632,19 +637,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     //   slice 1: H1 | barrier: buffer `cur` is free, the other buffer's DMA has landed | H2 with DMA slots,
     //            reading the first fragments of the next K-tile from the other buffer.
     // No branch encloses an MFMA (see k_gemm).
-#define MIRX_KTILE(KT)                                                                             \
-    MIRX_H1_HEAD(0, 0)                                                                             \
+#define MIRX_KTILE(KT, Z)                                                                          \
+    MIRX_H1_HEAD(0, 0, Z)                                                                          \
     MIRX_SLOT_B(0, 2)                                                                              \
-    MIRX_MFMA2(1, 0)                                                                               \
+    MIRX_MFMA2Z(1, 0, Z)                                                                           \
     MIRX_SLOT_B(1, 2)                                                                              \
-    MIRX_MFMA2(2, 0)                                                                               \
+    MIRX_MFMA2Z(2, 0, Z)                                                                           \
     MIRX_SLOT_B(0, 3)                                                                              \
-    MIRX_MFMA2(3, 0)                                                                               \
+    MIRX_MFMA2Z(3, 0, Z)                                                                           \
     MIRX_SLOT_B(1, 3)                                                                              \
-    MIRX_MFMA2(4, 0) MIRX_MFMA2(5, 0) MIRX_MFMA2(6, 0) MIRX_MFMA2(7, 0)                            \
+    MIRX_MFMA2Z(4, 0, Z) MIRX_MFMA2Z(5, 0, Z) MIRX_MFMA2Z(6, 0, Z) MIRX_MFMA2Z(7, 0, Z)            \
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
-    MIRX_H2(0, 1)                                                                                  \
-    MIRX_H1_HEAD(0, 1)                                                                             \
+    MIRX_H2(0, 1, Z)                                                                               \
+    MIRX_H1_HEAD(0, 1, 0)                                                                          \
     MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0)                            \
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
     MIRX_KBARRIER(); /* last reads of `cur` returned; the other buffer's DMA (mine) landed */      \
@@ -690,16 +695,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         const bool have_next = gt_nx < plan.ngt;
         const __amdgpu_buffer_rsrc_t rsrc_a_nx = make_rsrc_a(have_next ? gt_nx : gt);
 
-#pragma unroll
-        for (int mi = 0; mi < M_REP; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < N_REP; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.0f;
-
+        MIRX_KTILE(0, 1)                               // the first slice initialises the accumulators
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            MIRX_KTILE(kt)
+        for (int kt = 1; kt < nk; ++kt) {
+            MIRX_KTILE(kt, 0)
         }
 
         epilogue(gt);
@@ -723,6 +722,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #undef MIRX_DMA_AT_BARRIER
 #undef MIRX_H2_ROW
 #undef MIRX_MFMA2
+#undef MIRX_MFMA2Z
+#undef MIRX_H2_ROWZ
 #undef MIRX_LDA
 #undef MIRX_LDB
 }
