@@ -1,0 +1,200 @@
+// k_conv3x3.hip -- the 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1,
+// no bias) as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32, writing its 32 channels straight into
+// the block buffer (the separate copy of the new channels disappears).
+//
+// Replaces conv2 of torchvision's _DenseLayer (model.py:53 `densenet121`) on the 56x56, 28x28 and 14x14
+// maps (blocks 1-3: 96 % of the 3x3 time); the 7x7 maps stay with the library.
+//
+//   Y = A^T [ sum_c (G g G^T)_c  .  (B^T d_c B) ] A        per 2x2 output tile, 16 products instead of 36
+//
+// The sum over the 128 input channels of each of the 16 Winograd components is a GEMM
+//   M_xi[oc, tile] = sum_c U_xi[oc, c] V_xi[c, tile],   xi = (i, j) in 4 x 4.
+// One workgroup = one strip of up to 28 tiles of one image (one tile row of a 56-wide map, two of a
+// 28-wide one, four of a 14-wide one) = 28 MFMA columns (4 idle).  Wave i owns Winograd row i: it forms T_i = row i of B^T d from TWO
+// input rows, the four V_ij = T_i B with 8 adds per (tile, channel), and runs four MFMA chains
+// (j = 0..3) -- the transformed input never exists in memory.  U (transformed weights, prepared once
+// by the caller) and the raw input rows are staged 8 channels at a time through LDS (register
+// prefetched, 47 KiB, three workgroups per CU).  The output transform first folds j inside the wave
+// (P_i0 = M_i0 + M_i1 + M_i2, P_i1 = M_i1 - M_i2 - M_i3), exchanges the P's through LDS and finishes
+// with Y_0p = P_0p + P_1p + P_2p, Y_1p = P_1p - P_2p - P_3p.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int CIN = 128, COUT = 32;
+constexpr int KC = 8;                         // channels per stage
+constexpr int NCH = CIN / KC;                 // 16 stages
+constexpr int U_STAGE = 16 * KC * COUT;       // floats of transformed weights per stage (16 KiB)
+
+// W = map side (56 / 28 / 14); R = tile rows per strip (1 / 2 / 4): 28 tiles per strip; the last strip of
+// a 14-wide map holds three tile rows
+template <int W, int R>
+__global__ __launch_bounds__(256) void k_conv3x3_wino(const float *__restrict__ x, const float *__restrict__ u,
+                                                      float *__restrict__ out, int64_t out_bs) {
+    constexpr int TW = W / 2;                 // tiles per row
+    constexpr int ROWS = 2 * R + 2;           // input rows of a strip
+    constexpr int PITCH = W + 4;              // input row pitch in LDS: col -1 at index 1, even, >= W + 3
+    constexpr int IN_STAGE = KC * ROWS * PITCH;
+    constexpr int XB = 2 * COUT * 32;         // floats one wave writes to the exchange buffer
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *s_u = sm;                          // [2][16][KC][32]
+    float *s_in = sm + 2 * U_STAGE;           // [2][KC][ROWS][PITCH]
+    float *s_x = sm;                          // [4 waves][2][32 oc][32 tiles], after the K loop
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, n = lane & 31;
+    const int strip = blockIdx.x;
+    const int64_t img = blockIdx.y;
+    const int oy0 = strip * 2 * R;                           // first output row of the strip
+    const float *xi = x + img * CIN * (int64_t)(W * W);
+
+    // ---- staging assignments ------------------------------------------------------------------------
+    // weights: stage block is 4096 contiguous floats -> 4 float4 per thread
+    // input: KC * ROWS rows of W floats as float2 pairs; thread t takes items t, t + 256, ...
+    constexpr int IN_F2 = KC * ROWS * (W / 2);
+    constexpr int IN_PER = (IN_F2 + 255) / 256;
+    f32x4 ru[4];
+    float2 rin[IN_PER];
+    auto load = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ru[i] = *reinterpret_cast<const f32x4 *>(u + (int64_t)ch * U_STAGE + 4 * (threadIdx.x + 256 * i));
+#pragma unroll
+        for (int i = 0; i < IN_PER; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            const int c = it / (ROWS * (W / 2)), r = (it / (W / 2)) % ROWS, q = it % (W / 2);
+            const int iy = oy0 - 1 + r;
+            rin[i] = make_float2(0.f, 0.f);
+            if (it < IN_F2 && iy >= 0 && iy < W)
+                rin[i] = *reinterpret_cast<const float2 *>(xi + ((int64_t)(ch * KC + c) * W + iy) * W + 2 * q);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(s_u + buf * U_STAGE + 4 * (threadIdx.x + 256 * i)) = ru[i];
+#pragma unroll
+        for (int i = 0; i < IN_PER; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            const int c = it / (ROWS * (W / 2)), r = (it / (W / 2)) % ROWS, q = it % (W / 2);
+            if (it < IN_F2) {
+                float *d = s_in + buf * IN_STAGE + (c * ROWS + r) * PITCH + 1 + 2 * q;     // col x at index x + 1
+                d[0] = rin[i].x; d[1] = rin[i].y;
+            }
+        }
+    };
+    // the halo columns (x = -1 and x = W) are zero in both buffers for the whole kernel
+    for (int i = threadIdx.x; i < 2 * KC * ROWS; i += 256) {
+        float *row = s_in + (i / (KC * ROWS)) * IN_STAGE + (i % (KC * ROWS)) * PITCH;
+        row[0] = 0.f;
+        row[W + 1] = 0.f;
+        row[W + 2] = 0.f;
+        row[W + 3] = 0.f;
+    }
+
+    // ---- this lane's tile and this wave's pair of input rows --------------------------------------------
+    const int tile = n < R * TW ? n : R * TW - 1;            // idle lanes shadow the last tile (never stored)
+    const int tr = tile / TW, tc = tile % TW;
+    // T_i = s_a * d[ra] + s_b * d[rb]:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const int in_a = (2 * tr + ra) * PITCH + 2 * tc;         // + channel * ROWS * PITCH; cols 2tc-1 .. 2tc+2 at +0..+3
+    const int in_b = (2 * tr + rb) * PITCH + 2 * tc;
+    const int u_off = wave * 4 * KC * COUT + n;              // + (j * KC + c) * 32
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    load(0);
+    store(0);
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int cur = ch & 1;
+        __syncthreads();                                   // stage ch visible; buffer cur ^ 1 free
+        const int nxt = ch + 1 < NCH ? ch + 1 : ch;         // branch-free: the last stage re-loads itself
+        load(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *su = s_u + cur * U_STAGE + u_off;
+        const float *si = s_in + cur * IN_STAGE;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int c = 2 * s + half;
+            const float2 a0 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_a);
+            const float2 a1 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_a + 2);
+            const float2 b0 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_b);
+            const float2 b1 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_b + 2);
+            const float t0 = fmaf(sb, b0.x, a0.x), t1 = fmaf(sb, b0.y, a0.y);
+            const float t2 = fmaf(sb, b1.x, a1.x), t3 = fmaf(sb, b1.y, a1.y);
+            const float v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(0 * KC + c) * COUT], v0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(1 * KC + c) * COUT], v1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(2 * KC + c) * COUT], v2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(3 * KC + c) * COUT], v3, acc[3], 0, 0, 0);
+        }
+        store(cur ^ 1);
+    }
+
+    // ---- output transform ---------------------------------------------------------------------------------
+    __syncthreads();                                       // every wave is done with the staging buffers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
+        const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
+        const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
+        s_x[wave * XB + oc * 32 + n] = p0;
+        s_x[wave * XB + COUT * 32 + oc * 32 + n] = p1;
+    }
+    __syncthreads();
+    // item = (oc, tile): 32 x 28 items, 256 threads; lanes walk tiles -> coalesced float2 stores
+    float *oi = out + img * out_bs;
+    for (int it = threadIdx.x; it < COUT * 32; it += 256) {
+        const int oc = it >> 5, t = it & 31;
+        if (t < R * TW && oy0 + 2 * (t / TW) < W) {
+            const int otr = t / TW, otc = t % TW;
+            float p[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p[i][0] = s_x[i * XB + oc * 32 + t];
+                p[i][1] = s_x[i * XB + COUT * 32 + oc * 32 + t];
+            }
+            float *o = oi + ((int64_t)oc * W + oy0 + 2 * otr) * W + 2 * otc;
+            *reinterpret_cast<float2 *>(o) = make_float2(p[0][0] + p[1][0] + p[2][0], p[0][1] + p[1][1] + p[2][1]);
+            *reinterpret_cast<float2 *>(o + W) = make_float2(p[1][0] - p[2][0] - p[3][0], p[1][1] - p[2][1] - p[3][1]);
+        }
+    }
+}
+
+template <int W, int R>
+hipError_t launch_w(const float *x, const float *u, int64_t n, float *out, int64_t out_bs, hipStream_t st) {
+    constexpr int ROWS = 2 * R + 2, PITCH = W + 4;
+    const size_t stage = (size_t)(2 * U_STAGE + 2 * KC * ROWS * PITCH) * sizeof(float);
+    const size_t xch = (size_t)4 * 2 * COUT * 32 * sizeof(float);
+    const size_t lds = stage > xch ? stage : xch;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_wino<W, R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_conv3x3_wino<W, R>), dim3((W / 2 + R - 1) / R, (unsigned)n), dim3(256), lds, st, x, u, out,
+                       out_bs);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
+                               hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535) return hipErrorInvalidValue;
+    if (side == 56) return launch_w<56, 1>(x, u, n, out, out_bs, st);
+    if (side == 28) return launch_w<28, 2>(x, u, n, out, out_bs, st);
+    if (side == 14) return launch_w<14, 4>(x, u, n, out, out_bs, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mirx

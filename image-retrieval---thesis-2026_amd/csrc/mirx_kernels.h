@@ -54,6 +54,10 @@ hipError_t launch_topk_merge(const double *in_scores, const int64_t *in_ids, int
                              int64_t nq, int k, int metric, double *out_f64, float *out_val,
                              int64_t *out_ids, hipStream_t st);
 
+// ---- k_conv3x3.hip ----------------------------------------------------------------------
+hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
+                               hipStream_t st);
+
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                             hipStream_t st);

@@ -103,7 +103,7 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
     return out
 
 
-def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None):
+def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hip_conv3x3=True):
     """Inference path of one dense block (CUDA, eval):
        per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
@@ -114,7 +114,7 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None):
     buf[:, : block.cin] = x
     c = block.cin
     for name, layer in block.items():
-        sc1, sh1, w1, b1, ones, w1t = cache[name]
+        sc1, sh1, w1, b1, ones, w1t, u3 = cache[name]
         if use_hip_conv1x1:
             # norm1 + relu1 + conv1 + norm2 + relu2 in ONE fp32-MFMA pass over the buffer prefix
             y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
@@ -123,7 +123,14 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None):
                                                 _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
                        "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
-            buf[:, c: c + GROWTH] = F.conv2d(y, layer.conv2.weight, None, padding=1)
+            if use_hip_conv3x3 and h == w and h in (56, 28, 14) and b <= 65535:
+                # Winograd F(2x2,3x3) on fp32 MFMA, written straight into this layer's slice of the buffer
+                _lib.check(lib.mirx_conv3x3_winograd_nchw(_ptr(y), _ptr(u3), b, h,
+                                                          ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w),
+                                                          block.cout * h * w, _stream(x.device)),
+                           "mirx_conv3x3_winograd_nchw")
+            else:
+                buf[:, c: c + GROWTH] = F.conv2d(y, layer.conv2.weight, None, padding=1)
             c += GROWTH
             continue
         y = _fused_bn_relu(lib, buf, c, sc1, sh1)
@@ -195,6 +202,17 @@ def _make_features():
     return feats, c
 
 
+def _winograd_weights(w):
+    """conv2 weights [32, 128, 3, 3] -> U = G g G^T of Winograd F(2x2,3x3), laid out for
+    mirx_conv3x3_winograd_nchw: [stage = c // 8][xi = 4 i + j][c % 8][oc], fp32."""
+    g = w.detach().float()
+    gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], device=g.device)
+    u = torch.einsum("ik,ockl,jl->ocij", gm, g, gm)                       # [oc, c, 4, 4]
+    oc, cin = u.shape[0], u.shape[1]
+    u = u.reshape(oc, cin // 8, 8, 16).permute(1, 3, 2, 0)                # [stage, xi, c % 8, oc]
+    return u.contiguous()
+
+
 def _bn_affine(bn):
     """Eval-mode BatchNorm as y = x*scale + shift (fp32)."""
     scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -228,6 +246,7 @@ class DenseNet121(nn.Module):
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
         self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
+        self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:
@@ -268,7 +287,7 @@ class DenseNet121(nn.Module):
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
                     w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
-                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t)
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t, _winograd_weights(layer.conv2.weight))
                 cache[name] = blk
             elif name.startswith("transition"):
                 wt = m.conv.weight.detach().float()
@@ -296,7 +315,8 @@ class DenseNet121(nn.Module):
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
         for name, m in f.named_children():
             if name.startswith("denseblock"):
-                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer)
+                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer,
+                                       self.use_hip_conv3x3)
             elif name.startswith("transition"):
                 x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer)
         return x

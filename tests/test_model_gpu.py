@@ -144,3 +144,34 @@ def test_fused_conv1x1_kernel():
         assert rc == 0, lib.mirx_last_error()
         torch.cuda.synchronize()
         torch.testing.assert_close(y.cpu(), want, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,batch", [(56, 3), (28, 5), (14, 9)])
+def test_winograd_conv3x3_matches_direct_conv(side, batch):
+    """mirx_conv3x3_winograd_nchw (conv2 of a dense layer, model.py:53) against a float64 direct
+    convolution, written into a channel slice of a wider buffer.  Winograd F(2x2,3x3) in fp32: tolerance
+    2e-5 relative to the largest output (the same transform MIOpen's library kernel uses)."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _winograd_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side)
+    x = torch.randn(batch, 128, side, side, generator=g, device=dev)
+    w = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    buf = torch.full((batch, 96, side, side), 7.0, device=dev)
+    c0 = 40
+    u = _winograd_weights(w)
+    assert u.shape == (16, 16, 8, 32)
+    _lib.check(lib.mirx_conv3x3_winograd_nchw(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(u.data_ptr()), batch, side,
+                                              ctypes.c_void_p(buf.data_ptr() + 4 * c0 * side * side), 96 * side * side,
+                                              None), "conv3x3")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    got = buf[:, c0:c0 + 32].double().cpu()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    assert bool((buf[:, :c0] == 7.0).all()) and bool((buf[:, c0 + 32:] == 7.0).all())      # neighbours untouched
+    rc = lib.mirx_conv3x3_winograd_nchw(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(u.data_ptr()), batch, 7,
+                                        ctypes.c_void_p(buf.data_ptr()), 96 * side * side, None)
+    assert rc == -1
