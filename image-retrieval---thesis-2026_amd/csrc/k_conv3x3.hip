@@ -34,7 +34,7 @@ constexpr int U_STAGE = 16 * KC * COUT;       // floats of transformed weights p
 // W = map side (56 / 28 / 14); R = tile rows per strip (1 / 2 / 4): 28 tiles per strip; the last strip of
 // a 14-wide map holds three tile rows
 template <int W, int R>
-__global__ __launch_bounds__(256) void k_conv3x3_wino(const float *__restrict__ x, const float *__restrict__ u,
+__global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict__ x, const float *__restrict__ u,
                                                       float *__restrict__ out, int64_t out_bs) {
     constexpr int TW = W / 2;                 // tiles per row
     constexpr int ROWS = 2 * R + 2;           // input rows of a strip
@@ -123,21 +123,45 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const float *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         const float *su = s_u + cur * U_STAGE + u_off;
         const float *si = s_in + cur * IN_STAGE;
-#pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
-            const int c = 2 * s + half;
-            const float2 a0 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_a);
-            const float2 a1 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_a + 2);
-            const float2 b0 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_b);
-            const float2 b1 = *reinterpret_cast<const float2 *>(si + c * ROWS * PITCH + in_b + 2);
-            const float t0 = fmaf(sb, b0.x, a0.x), t1 = fmaf(sb, b0.y, a0.y);
-            const float t2 = fmaf(sb, b1.x, a1.x), t3 = fmaf(sb, b1.y, a1.y);
-            const float v0 = t0 - t2, v1 = t1 + t2, v2 = t2 - t1, v3 = t1 - t3;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(0 * KC + c) * COUT], v0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(1 * KC + c) * COUT], v1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(2 * KC + c) * COUT], v2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(3 * KC + c) * COUT], v3, acc[3], 0, 0, 0);
-        }
+        // operands of step s (channels 2s + half): two input rows x 4 columns, four weights.  Step s + 1 is
+        // read while the MFMAs of step s run (hipcc otherwise waits for every read right before its use).
+        float2 da[2][2], db[2][2];
+        float uw[2][4];
+#define MIRX_W_READ(S, SET)                                                                    \
+    {                                                                                          \
+        const int c_ = 2 * (S) + half;                                                         \
+        da[SET][0] = *reinterpret_cast<const float2 *>(si + c_ * ROWS * PITCH + in_a);         \
+        da[SET][1] = *reinterpret_cast<const float2 *>(si + c_ * ROWS * PITCH + in_a + 2);     \
+        db[SET][0] = *reinterpret_cast<const float2 *>(si + c_ * ROWS * PITCH + in_b);         \
+        db[SET][1] = *reinterpret_cast<const float2 *>(si + c_ * ROWS * PITCH + in_b + 2);     \
+        uw[SET][0] = su[(0 * KC + c_) * COUT];                                                 \
+        uw[SET][1] = su[(1 * KC + c_) * COUT];                                                 \
+        uw[SET][2] = su[(2 * KC + c_) * COUT];                                                 \
+        uw[SET][3] = su[(3 * KC + c_) * COUT];                                                 \
+    }
+#define MIRX_W_MFMA(SET)                                                                       \
+    {                                                                                          \
+        const float t0 = fmaf(sb, db[SET][0].x, da[SET][0].x), t1 = fmaf(sb, db[SET][0].y, da[SET][0].y); \
+        const float t2 = fmaf(sb, db[SET][1].x, da[SET][1].x), t3 = fmaf(sb, db[SET][1].y, da[SET][1].y); \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(uw[SET][0], t0 - t2, acc[0], 0, 0, 0);   \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(uw[SET][1], t1 + t2, acc[1], 0, 0, 0);   \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uw[SET][2], t2 - t1, acc[2], 0, 0, 0);   \
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(uw[SET][3], t1 - t3, acc[3], 0, 0, 0);   \
+    }
+        MIRX_W_READ(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        MIRX_W_READ(1, 1)
+        MIRX_W_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        MIRX_W_READ(2, 0)
+        MIRX_W_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        MIRX_W_READ(3, 1)
+        MIRX_W_MFMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        MIRX_W_MFMA(1)
+#undef MIRX_W_READ
+#undef MIRX_W_MFMA
         store(cur ^ 1);
     }
 
