@@ -175,3 +175,17 @@ def test_winograd_conv3x3_matches_direct_conv(side, batch):
     rc = lib.mirx_conv3x3_winograd_nchw(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(u.data_ptr()), batch, 7,
                                         ctypes.c_void_p(buf.data_ptr()), 96 * side * side, None)
     assert rc == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(256, 256), (160, 192), (112, 112)])
+def test_embeddings_at_other_resolutions(model_and_sd, size):
+    """Inputs whose feature maps are not 56/28/14/7 (the reference resizes to 224, read_data.py, but the
+    module accepts any size): the specialised kernels must step aside or generalise, never mis-index.
+    112x112 exercises the Winograd kernel on the 28- and 14-wide maps of blocks 1 and 2."""
+    m, sd = model_and_sd
+    x = torch.randn(3, 3, size[0], size[1], generator=torch.Generator().manual_seed(size[0]))
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+        ref = OD.embed(x, sd)
+    assert float((y - ref).abs().max()) <= 1e-5, float((y - ref).abs().max())
