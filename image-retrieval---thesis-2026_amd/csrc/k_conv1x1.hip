@@ -13,6 +13,8 @@
 // channels x 64 pixels, 4 waves as 2 (channels) x 2 (pixels), K staged 16 channels at a time through
 // a double-buffered LDS image (A = W^T [k][128], B = act [k][64], 16 channels per stage); both operand reads are one
 // ds_read_b32 per lane with consecutive lanes on consecutive words (conflict-free).
+#include <cstdlib>
+
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -43,10 +45,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
     // Staging assignments.  A (weights): thread -> rows a_k and a_k + 8, channels 4 a_m4 .. +3.
     // B (activations), VEC4: thread -> row b_k, pixels 4 b_p4 .. +3; scalar path (7x7 maps, hw % 4 != 0):
     // thread -> pixel tid % 64, rows tid / 64 + 4 i.  Out-of-range pixels read pixel 0 (never stored).
-    static_assert(KC == 16 && NREP == 1, "staging below is written for 16-channel stages of 64 pixels");
+    // With NREP = 2 (128-pixel tile, VEC4 only) a thread stages rows b_k and b_k + 8 of its 4 pixels.
+    static_assert(KC == 16 && (NREP == 1 || (NREP == 2 && VEC4)), "staging below is written for 16-channel stages");
     const int a_k = threadIdx.x >> 5, a_m4 = threadIdx.x & 31;
-    const int b_k = VEC4 ? threadIdx.x >> 4 : threadIdx.x >> 6;
-    const int b_p = VEC4 ? 4 * (threadIdx.x & 15) : threadIdx.x & 63;
+    const int b_k = VEC4 ? threadIdx.x / (16 * NREP) : threadIdx.x >> 6;
+    const int b_p = VEC4 ? 4 * (threadIdx.x % (16 * NREP)) : threadIdx.x & 63;
     int64_t b_off = 0;
     {
         const int64_t pp = p0 + b_p;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
     // Register-prefetched, branch-free pipeline: the global loads of stage kt+1 are issued before the
     // MFMAs of stage kt and written to the idle LDS buffer after them (the last iteration re-stages its
     // own K slice into the idle buffer, which nobody reads).
-    float4 ra0, ra1, rb;
+    float4 ra0, ra1, rb, rb2;
     float rs0, rs1, rs2, rs3, sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f, sc2 = 1.f, sh2 = 0.f, sc3 = 1.f, sh3 = 0.f;
 #define MIRX_C1_LOAD(k0)                                                                           \
     do {                                                                                           \
@@ -67,6 +70,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         if (VEC4) {                                                                                \
             rb = *reinterpret_cast<const float4 *>(xsrc + (int64_t)(k0) * hw);                     \
             if (PROLOGUE) { sc0 = scale[(k0) + b_k]; sh0 = shift[(k0) + b_k]; }                    \
+            if (NREP == 2) {                                                                       \
+                rb2 = *reinterpret_cast<const float4 *>(xsrc + (int64_t)((k0) + 8) * hw);          \
+                if (PROLOGUE) { sc1 = scale[(k0) + b_k + 8]; sh1 = shift[(k0) + b_k + 8]; }        \
+            }                                                                                      \
         } else {                                                                                   \
             rs0 = xsrc[(int64_t)(k0) * hw];                                                        \
             rs1 = xsrc[(int64_t)((k0) + 4) * hw];                                                  \
@@ -90,6 +97,11 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
             v.x = MIRX_C1_ACT(rb.x, sc0, sh0); v.y = MIRX_C1_ACT(rb.y, sc0, sh0);                  \
             v.z = MIRX_C1_ACT(rb.z, sc0, sh0); v.w = MIRX_C1_ACT(rb.w, sc0, sh0);                  \
             *reinterpret_cast<float4 *>(&sB[buf][b_k][b_p]) = v;                                   \
+            if (NREP == 2) {                                                                       \
+                v.x = MIRX_C1_ACT(rb2.x, sc1, sh1); v.y = MIRX_C1_ACT(rb2.y, sc1, sh1);            \
+                v.z = MIRX_C1_ACT(rb2.z, sc1, sh1); v.w = MIRX_C1_ACT(rb2.w, sc1, sh1);            \
+                *reinterpret_cast<float4 *>(&sB[buf][b_k + 8][b_p]) = v;                           \
+            }                                                                                      \
         } else {                                                                                   \
             sB[buf][b_k][b_p] = MIRX_C1_ACT(rs0, sc0, sh0);                                        \
             sB[buf][b_k + 4][b_p] = MIRX_C1_ACT(rs1, sc1, sh1);                                    \
@@ -98,17 +110,19 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         }                                                                                          \
     } while (0)
 
-    f32x16 acc[2];
+    f32x16 acc[2][NREP];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        for (int ni = 0; ni < NREP; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nk = cin / KC;
     if (threadIdx.x < CM) sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
     MIRX_C1_LOAD(0);
     MIRX_C1_STORE(0);
-    const int kh = lane >> 5, nn = wn * 32 + (lane & 31), m0 = wm * 64 + (lane & 31);
+    const int kh = lane >> 5, nn = wn * 32 * NREP + (lane & 31), m0 = wm * 64 + (lane & 31);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();                                   // stage kt visible; buffer cur^1 free
@@ -117,11 +131,16 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
         __builtin_amdgcn_sched_barrier(0);                 // keep the loads ahead of the MFMAs
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            const float bv = sB[cur][2 * kk + kh][nn];
+            float bv[NREP];
+#pragma unroll
+            for (int ni = 0; ni < NREP; ++ni) bv[ni] = sB[cur][2 * kk + kh][nn + 32 * ni];
             const float a0 = sA[cur][2 * kk + kh][m0];
             const float a1 = sA[cur][2 * kk + kh][m0 + 32];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NREP; ++ni) {
+                acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[ni], acc[0][ni], 0, 0, 0);
+                acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[ni], acc[1][ni], 0, 0, 0);
+            }
         }
         MIRX_C1_STORE(cur ^ 1);
     }
@@ -131,9 +150,10 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 32 NREP wn + 32 ni + (lane & 31)
-    {
-        const int64_t pp = p0 + wn * 32 + (lane & 31);
-        if (pp >= total) return;
+#pragma unroll
+    for (int ni = 0; ni < NREP; ++ni) {
+        const int64_t pp = p0 + wn * 32 * NREP + 32 * ni + (lane & 31);
+        if (pp >= total) continue;
         const int64_t bimg = pp / hw, off = pp % hw;
         float *yo = y + bimg * (int64_t)cout * hw + off;
 #pragma unroll
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float *__restrict__ x, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[mi][r] + sBias[ch - co0];
+                float v = acc[mi][ni][r] + sBias[ch - co0];
                 if (RELU_OUT) v = fmaxf(v, 0.f);
                 yo[(int64_t)ch * hw] = v;
             }
@@ -172,13 +192,15 @@ hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *sca
                           hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % 32 || cout % CM) return hipErrorInvalidValue;
-    // NREP = 1 (64-pixel tiles, 48 KiB LDS, 3 workgroups per CU) measured faster than NREP = 2
-    // (128-pixel tiles, 2 per CU) on every DenseNet-121 layer shape: 13.6k vs 13.3k img/s end to end
-    // Tile choice measured on DenseNet-121 (B = 256, end-to-end img/s): 64 pixels x 16 channels per
-    // stage (24 KiB LDS, 6 workgroups per CU) 14.07k; 64 x 32: 13.62k; 64 x 8: 13.39k; 128 x 16: 13.47k;
-    // 128 x 32: 13.24k -- occupancy beats weight-tile reuse here.
-    if ((hw & 3) == 0 && (xbs & 3) == 0)
+    // Tile choice, measured on DenseNet-121 end to end: 64 pixels x 16 channels per stage (24 KiB LDS, 6
+    // workgroups per CU) is the default; 64 x 32 and 64 x 8 channel stages were 3-5 % slower.  A 128-pixel
+    // tile (NREP = 2, weights reused twice, MIRX_C1_NREP=2) is within 1.5 % either way per layer since the
+    // K loop prefetches through registers (24.8 vs 25.1 ms over the 61 launches of a 1024-image forward).
+    if ((hw & 3) == 0 && (xbs & 3) == 0) {
+        static const int nrep = [] { const char *e = getenv("MIRX_C1_NREP"); return e && e[0] == '2' ? 2 : 1; }();
+        if (nrep == 2) return launch_v<true, 2, 16>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
         return launch_v<true, 1, 16>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
+    }
     return launch_v<false, 1, 16>(x, xbs, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y, st);
 }
 
