@@ -25,6 +25,7 @@
 //     has several MFMAs of cover before its first use;
 //   * the barrier sits in front of the LAST slice of a tile: that slice's fragments are already
 //     in registers, so its MFMAs cover the DMA issue and the first reads of tile kt+1.
+#include <cstdio>
 #include <cstdlib>
 
 #include "mirx_kernels.h"
@@ -479,33 +480,42 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // rows beyond the gallery exist only in its last (partial) tile: test them only there
+        const bool partial = (tile_row0 + WM_ROWS) * A.row_stride > A.n_rows;
 #pragma unroll
         for (int ni = 0; ni < N_REP; ++ni) {
+            // maximum per row tile first: the candidate path below then looks only inside row tiles that
+            // hold a passing score (about two scores per wave and gallery tile pass, out of 2048)
+            float mrow[M_REP];
             float mx = -INFINITY;
 #pragma unroll
-            for (int mi = 0; mi < M_REP; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
+            for (int mi = 0; mi < M_REP; ++mi) {
+                mrow[mi] = fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3]));
+                mx = fmaxf(mx, mrow[mi]);
+            }
             if (MODE == 1) {
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 if (quad == 0)
                     A.groupmax[(q_row0 + wn * 64 + ni * 16 + col) * A.ngroups + gt_ * WARPS_M + wm] = mx;
             } else if (__any(mx > tau[ni])) {
-                // rare path, see k_gemm.  The four lanes that share a query (lane & 15) claim consecutive
-                // slots in one step: rank among the passing lanes of the same query, by ballot.
+                // Candidate path.  No global atomics: the region (query, this workgroup's phase, this wave
+                // row) belongs to this wave alone and its fill count lives in LDS.  The four lanes that share
+                // a query (lane & 15) claim consecutive slots in one step: rank among the passing lanes of
+                // the same query, by ballot.  Rows beyond the region's slots go to the query's overflow list.
                 const int64_t qc = q_row0 + wn * 64 + ni * 16 + col;
                 const int cidx = (wn * 64 + ni * 16 + col) * WARPS_M + wm;
                 Cand *dst = A.cand + (qc * A.regions + region) * A.slots;
                 const unsigned long long mine = 0x0001000100010001ull << col;
                 const unsigned long long below = mine & ((1ull << el) - 1ull);
 #pragma unroll
-                for (int mi = 0; mi < M_REP; ++mi)
+                for (int mi = 0; mi < M_REP; ++mi) {
+                    if (!__any(mrow[mi] > tau[ni])) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = acc[mi][ni][r];
                         const int64_t grow = (tile_row0 + mi * 16 + 4 * quad + r) * A.row_stride;
-                        const bool pass = v > tau[ni] && grow < A.n_rows;
+                        const bool pass = v > tau[ni] && (!partial || grow < A.n_rows);
                         const unsigned long long pm = __ballot(pass);
                         if (pm != 0) {
                             const int base = lcnt[cidx];
@@ -525,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                             }
                         }
                     }
+                }
             }
         }
     };
@@ -570,14 +581,26 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         dma_a = smem + cur * A_TILE_BYTES + wave * 1024;                            \
         dma_b = smem + LDS_B0 + cur * B_TILE_BYTES + wave * 1024;                   \
     }
+    // diagnostic builds: -DMIRX_EXP_SLOTS=0 no DMA slots at all, =1 slot branches present but never taken
+    // (results wrong either way); -DMIRX_EXP_CYCLES prints K-loop cycles per K-tile
+#if defined(MIRX_EXP_SLOTS) && MIRX_EXP_SLOTS == 1
+#define MIRX_SLOT_COND(G) (grp == (G) && A.dimp < 0)
+#else
+#define MIRX_SLOT_COND(G) (grp == (G))
+#endif
+#if defined(MIRX_EXP_SLOTS) && MIRX_EXP_SLOTS == 0
+#define MIRX_SLOT_A(G, P)
+#define MIRX_SLOT_B(G, P)
+#else
 #define MIRX_SLOT_A(G, P)                                                           \
-    if (grp == (G))                                                                 \
+    if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, LDS_PTR(dma_a + (P) * 8192), 16, voff_a, \
                                                  dma_koff + (P) * pstride_a, 0, 0);
 #define MIRX_SLOT_B(G, P)                                                           \
-    if (grp == (G))                                                                 \
+    if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(dma_b + (P) * 8192), 16, voff_b, \
                                                  dma_koff + (P) * pstride_b, 0, 0);
+#endif
 
     // H1 of a slice: query tiles 0,1 of every row tile; B fragments 2,3 of the same slice are read early
 #define MIRX_H1_HEAD(OTHER, S, Z)                         \
@@ -685,6 +708,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     dma_koff = ROW_BYTES;
     dma_a = smem + A_TILE_BYTES + wave * 1024;
     dma_b = smem + LDS_B0 + B_TILE_BYTES + wave * 1024;
+#ifdef MIRX_EXP_CYCLES
+    unsigned long long cy_sum = 0, cy_n = 0, ep_sum = 0, ep_n = 0;
+    const unsigned long long life0 = __builtin_amdgcn_s_memtime();
+#endif
     // Waves 4-7 are the younger SIMD partners and lose every issue arbitration against waves 0-3, which
     // then wait for them at each barrier: a static priority for the younger half evens the two out
     // (bench: 5.75 -> 5.54 ms per 4096-query launch).
@@ -695,17 +722,37 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         const bool have_next = gt_nx < plan.ngt;
         const __amdgpu_buffer_rsrc_t rsrc_a_nx = make_rsrc_a(have_next ? gt_nx : gt);
 
+#ifdef MIRX_EXP_CYCLES
+        const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
+#endif
         MIRX_KTILE(0, 1)                               // the first slice initialises the accumulators
 #pragma unroll 1
         for (int kt = 1; kt < nk; ++kt) {
             MIRX_KTILE(kt, 0)
         }
+#ifdef MIRX_EXP_CYCLES
+        cy_sum += __builtin_amdgcn_s_memtime() - cy0;
+        cy_n += nk;
+#endif
 
+#ifdef MIRX_EXP_CYCLES
+        const unsigned long long ep0 = __builtin_amdgcn_s_memtime();
+#endif
         epilogue(gt);
+#ifdef MIRX_EXP_CYCLES
+        ep_sum += __builtin_amdgcn_s_memtime() - ep0;
+        ep_n += 1;
+#endif
         if (!have_next) break;
         gt = gt_nx;
         rsrc_a = rsrc_a_nx;
     }
+#ifdef MIRX_EXP_CYCLES
+    if (lane == 0 && (blockIdx.x % 61) == 0 && cy_n > 1000 && (wave == 0 || wave == 4))
+        printf("wg %d wave %d: %.0f cycles per K-tile in the K loop (%llu K-tiles); epilogue %.0f cycles per gallery tile; kernel %.0f cycles per K-tile\n",
+               (int)blockIdx.x, wave, (double)cy_sum / cy_n, cy_n, (double)ep_sum / ep_n,
+               (double)(__builtin_amdgcn_s_memtime() - life0) / cy_n);
+#endif
     if (MODE == 0) {
         __syncthreads();
         for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) {
