@@ -164,24 +164,49 @@ __global__ __launch_bounds__(256) void k_bn_relu(const float *__restrict__ x, in
     }
 }
 
-// avgpool2x2(relu(bn(x))): one thread per pair of horizontally adjacent outputs.
+// avgpool2x2(relu(bn(x))): one thread per pair of horizontally adjacent outputs = two 16-byte loads and
+// one 8-byte store; items are numbered (image, channel, output row, output column pair) in one flat grid
+// (odd output widths end each row with a single-output item).
 __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restrict__ x, int64_t xbs,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int c, int h,
-                                                          int w, float *__restrict__ y) {
-    const int64_t b = blockIdx.z;
-    const int ch = blockIdx.y;
-    const int oh = h >> 1, ow = w >> 1;
+                                                          int w, int64_t items, float *__restrict__ y) {
+    const int oh = h >> 1, ow = w >> 1, pw = (ow + 1) >> 1;
+    const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (it >= items) return;
+    const int px = (int)(it % pw);
+    const int64_t t1 = it / pw;
+    const int oy = (int)(t1 % oh);
+    const int64_t t2 = t1 / oh;
+    const int ch = (int)(t2 % c);
+    const int64_t b = t2 / c;
     const float sc = scale[ch], sh = shift[ch];
-    const float *xp = x + b * xbs + (int64_t)ch * h * w;
-    float *yp = y + (b * c + ch) * (int64_t)oh * ow;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < oh * ow; o += gridDim.x * 256) {
-        const int oy = o / ow, ox = o % ow;
-        const float2 r0 = *reinterpret_cast<const float2 *>(xp + (int64_t)(2 * oy) * w + 2 * ox);
-        const float2 r1 = *reinterpret_cast<const float2 *>(xp + (int64_t)(2 * oy + 1) * w + 2 * ox);
-        const float s = fmaxf(fmaf(r0.x, sc, sh), 0.0f) + fmaxf(fmaf(r0.y, sc, sh), 0.0f) +
-                        fmaxf(fmaf(r1.x, sc, sh), 0.0f) + fmaxf(fmaf(r1.y, sc, sh), 0.0f);
-        yp[o] = s * 0.25f;
+    const float *xp = x + b * xbs + ((int64_t)ch * h + 2 * oy) * w + 4 * px;
+    float *yp = y + ((b * c + ch) * (int64_t)oh + oy) * ow + 2 * px;
+    auto act = [&](float v) { return fmaxf(fmaf(v, sc, sh), 0.0f); };
+    if (2 * px + 1 < ow) {
+        float4 r0, r1;
+        if ((w & 3) == 0) {                                  // rows start 16-byte aligned
+            r0 = *reinterpret_cast<const float4 *>(xp);
+            r1 = *reinterpret_cast<const float4 *>(xp + w);
+        } else {
+            const float2 a0 = *reinterpret_cast<const float2 *>(xp), a1 = *reinterpret_cast<const float2 *>(xp + 2);
+            const float2 b0 = *reinterpret_cast<const float2 *>(xp + w), b1 = *reinterpret_cast<const float2 *>(xp + w + 2);
+            r0 = make_float4(a0.x, a0.y, a1.x, a1.y);
+            r1 = make_float4(b0.x, b0.y, b1.x, b1.y);
+        }
+        const float s0 = act(r0.x) + act(r0.y) + act(r1.x) + act(r1.y);
+        const float s1 = act(r0.z) + act(r0.w) + act(r1.z) + act(r1.w);
+        if ((ow & 1) == 0) {
+            *reinterpret_cast<float2 *>(yp) = make_float2(s0 * 0.25f, s1 * 0.25f);
+        } else {
+            yp[0] = s0 * 0.25f;
+            yp[1] = s1 * 0.25f;
+        }
+    } else {
+        const float2 r0 = *reinterpret_cast<const float2 *>(xp);
+        const float2 r1 = *reinterpret_cast<const float2 *>(xp + w);
+        yp[0] = (act(r0.x) + act(r0.y) + act(r1.x) + act(r1.y)) * 0.25f;
     }
 }
 
@@ -203,9 +228,10 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
                                    hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if ((h & 1) || (w & 1) || (x_batch_stride & 1) || n > 65535 || c > 65535) return hipErrorInvalidValue;
-    const int outs = (h / 2) * (w / 2);
-    hipLaunchKernelGGL(k_bn_relu_avgpool2, dim3((unsigned)((outs + 255) / 256), (unsigned)c, (unsigned)n),
-                       dim3(256), 0, st, x, x_batch_stride, scale, shift, c, h, w, y);
+    const int64_t items = n * c * (int64_t)(h / 2) * ((w / 2 + 1) / 2);
+    if ((items + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bn_relu_avgpool2, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, x_batch_stride,
+                       scale, shift, c, h, w, items, y);
     return hipGetLastError();
 }
 
