@@ -3,7 +3,7 @@
 // the block buffer (the separate copy of the new channels disappears).
 //
 // Replaces conv2 of torchvision's _DenseLayer (model.py:53 `densenet121`) on the 56x56, 28x28 and 14x14
-// maps (blocks 1-3: 96 % of the 3x3 time); the 7x7 maps stay with the library.
+// maps (k_conv3x3_wino) and on the 7x7 maps of the last block (k_conv3x3_wino7): all 58 dense layers.
 //
 //   Y = A^T [ sum_c (G g G^T)_c  .  (B^T d_c B) ] A        per 2x2 output tile, 16 products instead of 36
 //
@@ -195,6 +195,128 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict
     }
 }
 
+// The 7x7 maps (last dense block): a map is 4 x 4 tiles (the 8th row / column of outputs is computed and
+// dropped), so one workgroup takes TWO images = 32 tiles = all 32 MFMA columns.  Same algorithm and weight
+// layout as k_conv3x3_wino; the input is staged cell by cell (rows of 7 floats have no vector alignment)
+// into zero-initialised 10 x 12 planes whose border cells are never written.
+__global__ __launch_bounds__(256, 3) void k_conv3x3_wino7(const float *__restrict__ x, const float *__restrict__ u,
+                                                          float *__restrict__ out, int64_t out_bs, int64_t n_img) {
+    constexpr int W = 7, ROWS = 10, PITCH = 12;
+    constexpr int PLANE = ROWS * PITCH;                  // one channel of one image
+    constexpr int IN_STAGE = 2 * KC * PLANE;
+    constexpr int XB = 2 * COUT * 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *s_u = sm;                                     // [2][16][KC][32]
+    float *s_in = sm + 2 * U_STAGE;                      // [2][2 images][KC][ROWS][PITCH]
+    float *s_x = sm;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, n = lane & 31;
+    const int64_t img0 = (int64_t)blockIdx.x * 2;
+
+    // staging: weights 4 float4 per thread; input cells (image, channel, y, x): 2*8*49 = 784 -> 4 per thread
+    constexpr int CELLS = 2 * KC * W * W;
+    constexpr int IN_PER = (CELLS + 255) / 256;
+    f32x4 ru[4];
+    float rin[IN_PER];
+    auto load = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ru[i] = *reinterpret_cast<const f32x4 *>(u + (int64_t)ch * U_STAGE + 4 * (threadIdx.x + 256 * i));
+#pragma unroll
+        for (int i = 0; i < IN_PER; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            const int im = it / (KC * W * W), c = (it / (W * W)) % KC, cell = it % (W * W);
+            rin[i] = 0.f;
+            if (it < CELLS && img0 + im < n_img)
+                rin[i] = x[((img0 + im) * CIN + ch * KC + c) * (int64_t)(W * W) + cell];
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(s_u + buf * U_STAGE + 4 * (threadIdx.x + 256 * i)) = ru[i];
+#pragma unroll
+        for (int i = 0; i < IN_PER; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            const int im = it / (KC * W * W), c = (it / (W * W)) % KC, cell = it % (W * W);
+            if (it < CELLS)
+                s_in[buf * IN_STAGE + (im * KC + c) * PLANE + (cell / W + 1) * PITCH + cell % W + 1] = rin[i];
+        }
+    };
+    for (int i = threadIdx.x; i < 2 * IN_STAGE; i += 256) s_in[i] = 0.f;     // borders stay zero for good
+    __syncthreads();
+
+    const int im = n >> 4, tile = n & 15;
+    const int tr = tile >> 2, tc = tile & 3;
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const int in_a = im * KC * PLANE + (2 * tr + ra) * PITCH + 2 * tc;
+    const int in_b = im * KC * PLANE + (2 * tr + rb) * PITCH + 2 * tc;
+    const int u_off = wave * 4 * KC * COUT + n;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    load(0);
+    store(0);
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int cur = ch & 1;
+        __syncthreads();
+        const int nxt = ch + 1 < NCH ? ch + 1 : ch;
+        load(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const float *su = s_u + cur * U_STAGE + u_off;
+        const float *si = s_in + cur * IN_STAGE;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            const int c = 2 * s + half;
+            const float2 a0 = *reinterpret_cast<const float2 *>(si + c * PLANE + in_a);
+            const float2 a1 = *reinterpret_cast<const float2 *>(si + c * PLANE + in_a + 2);
+            const float2 b0 = *reinterpret_cast<const float2 *>(si + c * PLANE + in_b);
+            const float2 b1 = *reinterpret_cast<const float2 *>(si + c * PLANE + in_b + 2);
+            const float t0 = fmaf(sb, b0.x, a0.x), t1 = fmaf(sb, b0.y, a0.y);
+            const float t2 = fmaf(sb, b1.x, a1.x), t3 = fmaf(sb, b1.y, a1.y);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(0 * KC + c) * COUT], t0 - t2, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(1 * KC + c) * COUT], t1 + t2, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(2 * KC + c) * COUT], t2 - t1, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(su[(3 * KC + c) * COUT], t1 - t3, acc[3], 0, 0, 0);
+        }
+        store(cur ^ 1);
+    }
+
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
+        s_x[wave * XB + oc * 32 + n] = acc[0][r] + acc[1][r] + acc[2][r];
+        s_x[wave * XB + COUT * 32 + oc * 32 + n] = acc[1][r] - acc[2][r] - acc[3][r];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < COUT * 32; it += 256) {
+        const int oc = it >> 5, t = it & 31;
+        const int oim = t >> 4, otr = (t & 15) >> 2, otc = t & 3;
+        if (img0 + oim >= n_img) continue;
+        float p[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i][0] = s_x[i * XB + oc * 32 + t];
+            p[i][1] = s_x[i * XB + COUT * 32 + oc * 32 + t];
+        }
+        float *o = out + (img0 + oim) * out_bs + ((int64_t)oc * W + 2 * otr) * W + 2 * otc;
+        const bool col1 = 2 * otc + 1 < W, row1 = 2 * otr + 1 < W;
+        o[0] = p[0][0] + p[1][0] + p[2][0];
+        if (col1) o[1] = p[0][1] + p[1][1] + p[2][1];
+        if (row1) {
+            o[W] = p[1][0] - p[2][0] - p[3][0];
+            if (col1) o[W + 1] = p[1][1] - p[2][1] - p[3][1];
+        }
+    }
+}
+
 template <int W, int R>
 hipError_t launch_w(const float *x, const float *u, int64_t n, float *out, int64_t out_bs, hipStream_t st) {
     constexpr int ROWS = 2 * R + 2, PITCH = W + 4;
@@ -218,6 +340,14 @@ hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int si
     if (side == 56) return launch_w<56, 1>(x, u, n, out, out_bs, st);
     if (side == 28) return launch_w<28, 2>(x, u, n, out, out_bs, st);
     if (side == 14) return launch_w<14, 4>(x, u, n, out, out_bs, st);
+    if (side == 7) {
+        const size_t lds = (size_t)(2 * U_STAGE + 2 * 2 * KC * 10 * 12) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_wino7),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_conv3x3_wino7, dim3((unsigned)((n + 1) / 2)), dim3(256), lds, st, x, u, out, out_bs, n);
+        return hipGetLastError();
+    }
     return hipErrorInvalidValue;
 }
 

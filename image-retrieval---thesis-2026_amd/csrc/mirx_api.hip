@@ -634,7 +634,7 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
 int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_batch_stride,
                                void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3: batch must be in [0, 65535]");
-    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3: side must be 56, 28 or 14");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14 || side == 7, "conv3x3: side must be 56, 28, 14 or 7");
     MIRX_CHECK(n == 0 || (x && u && out), "conv3x3: null buffer");
     MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3: output batch stride too small");
     MIRX_HIP(launch_conv3x3_wino(x, u, n, side, out, out_batch_stride, reinterpret_cast<hipStream_t>(stream)));

@@ -123,7 +123,7 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
                                                 _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
                        "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
-            if use_hip_conv3x3 and h == w and h in (56, 28, 14) and b <= 65535:
+            if use_hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
                 # Winograd F(2x2,3x3) on fp32 MFMA, written straight into this layer's slice of the buffer
                 _lib.check(lib.mirx_conv3x3_winograd_nchw(_ptr(y), _ptr(u3), b, h,
                                                           ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w),
@@ -246,7 +246,7 @@ class DenseNet121(nn.Module):
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
         self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
-        self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 maps (False: MIOpen)
+        self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:

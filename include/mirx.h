@@ -159,7 +159,7 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
 /*
  * 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1, no bias): conv2 of
  * torchvision's _DenseLayer (model.py:53), as Winograd F(2x2,3x3) on fp32 MFMA.  x: device NCHW fp32
- * [n, 128, side, side] (packed), side = 56, 28 or 14.  u: device fp32 [16 stages][16][8][32] = the
+ * [n, 128, side, side] (packed), side = 56, 28, 14 or 7.  u: device fp32 [16 stages][16][8][32] = the
  * transformed weights U_xi[oc, c] = (G g G^T)_xi of the layer, stage s holding channels 8s .. 8s+7 as
  * [xi = 4i + j][c][oc] (mirx.model prepares it once per layer).  The 32 output channels of image b are
  * written at out + b * out_batch_stride as [32, side, side] -- i.e. directly into the layer's slice of

@@ -147,7 +147,7 @@ def test_fused_conv1x1_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("side,batch", [(56, 3), (28, 5), (14, 9)])
+@pytest.mark.parametrize("side,batch", [(56, 3), (28, 5), (14, 9), (7, 6), (7, 5)])
 def test_winograd_conv3x3_matches_direct_conv(side, batch):
     """mirx_conv3x3_winograd_nchw (conv2 of a dense layer, model.py:53) against a float64 direct
     convolution, written into a channel slice of a wider buffer.  Winograd F(2x2,3x3) in fp32: tolerance
@@ -172,7 +172,7 @@ def test_winograd_conv3x3_matches_direct_conv(side, batch):
     got = buf[:, c0:c0 + 32].double().cpu()
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
     assert bool((buf[:, :c0] == 7.0).all()) and bool((buf[:, c0 + 32:] == 7.0).all())      # neighbours untouched
-    rc = lib.mirx_conv3x3_winograd_nchw(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(u.data_ptr()), batch, 7,
+    rc = lib.mirx_conv3x3_winograd_nchw(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(u.data_ptr()), batch, 12,
                                         ctypes.c_void_p(buf.data_ptr()), 96 * side * side, None)
     assert rc == -1
 
