@@ -1,0 +1,220 @@
+// k_conv1x1_s3.hip -- the dense-layer 1x1 convolution of k_conv1x1.hip for the MFMA-bound layers
+// (many input channels, small maps), with each fp32 operand carried as THREE bf16 terms so that the
+// products run on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate):
+//     x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)      (exact: 3 x 8 = 24 bits)
+//     w * x ~= wh xh + wh xm + wm xh + wh xl + wl xh + wm xm                           (6 MFMAs, fp32 accumulate)
+// The dropped cross terms are <= 3 * 2^-24 |w x|: the rounding class of one fp32 product, so the result is
+// fp32-grade (tests: 2e-6 of the fp32 kernel).  6 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of 64
+// cycles per 16 channels: 2.67x less matrix-pipe time; the layer then runs against its HBM stream.
+//
+// Same contract as mirx_conv1x1_bn_relu (y = act_out(W * act_in(x) + bias), NCHW), except that the
+// weights arrive pre-split: w3 = [cout / 128][cin / 16][3 terms][128 out][16 in] bf16 (mirx.model
+// prepares it once per layer).  Workgroup tile 128 output channels x 128 pixels, 4 waves (2 x 2), one
+// 16-channel K step per stage, double-buffered LDS (48 KiB, 3 workgroups per CU), register prefetch.
+// Activations are split while they are staged: a thread owns one pixel and 8 consecutive channels (8
+// coalesced loads, BN + ReLU with wave-uniform scalars, three 16-byte LDS stores).  LDS rows are 32 B
+// (16 bf16); chunk c of row r sits at c ^ ((r >> 3) & 1): conflict-free ds_read_b128 for the hardware's
+// 16-lane groups.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int CM = 128;            // output channels per workgroup
+constexpr int CP = 128;            // pixels per workgroup
+constexpr int KC = 16;             // channels per stage
+constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage (4 KiB)
+constexpr int PLANE_B = CP * KC * 2;
+constexpr int STAGE = 3 * PLANE_A + 3 * PLANE_B;   // 24 KiB
+
+__device__ inline unsigned bf16_rne(float f) {      // finite inputs
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <bool PROLOGUE, bool RELU_OUT>
+__global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__ x, int64_t xbs, int cin,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift,
+                                                       const uint16_t *__restrict__ w3,
+                                                       const float *__restrict__ bias, int64_t n, int hw, int cout,
+                                                       float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    __shared__ float sBias[CM];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t total = n * (int64_t)hw;
+    const int64_t p0 = (int64_t)blockIdx.x * CP;
+    const int co0 = blockIdx.y * CM;
+    const int nk = cin / KC;
+
+    // ---- staging assignments ------------------------------------------------------------------------
+    // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
+    const int b_px = threadIdx.x & 127;
+    const int b_kg = wave >> 1;
+    int64_t b_off = 0;
+    {
+        const int64_t pp = p0 + b_px;
+        if (pp < total) b_off = (pp / hw) * xbs + (pp % hw);
+    }
+    const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * hw;
+    const int b_lds = 3 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + term * PLANE_B
+    // A: the stage block [3][128][16] bf16 is 768 chunks of 16 B; thread -> chunks t, t + 256, t + 512
+    const uint16_t *wsrc = w3 + ((int64_t)blockIdx.y * nk) * (3 * CM * KC) + threadIdx.x * 8;
+    int a_lds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = threadIdx.x + 256 * i;            // chunk id: term = ch >> 8, row = (ch >> 1) & 127, c = ch & 1
+        const int row = (ch >> 1) & 127;
+        a_lds[i] = (ch >> 8) * PLANE_A + row * 32 + (((ch & 1) ^ ((row >> 3) & 1)) << 4);
+    }
+
+    u32x4 ra[3];
+    float rb[8], rsc[8], rsh[8];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            ra[i] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (3 * CM * KC) + 2048 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = xsrc[((int64_t)kt * KC + j) * hw];
+        if (PROLOGUE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rsc[j] = scale[kt * KC + 8 * b_kg + j];
+                rsh[j] = shift[kt * KC + 8 * b_kg + j];
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        char *sb = sm + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4 *>(sb + a_lds[i]) = ra[i];
+        unsigned th[8], tm[8], tl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = rb[j];
+            if (PROLOGUE) v = fmaxf(fmaf(v, rsc[j], rsh[j]), 0.f);
+            th[j] = bf16_rne(v);
+            const float r1 = v - __uint_as_float(th[j] << 16);
+            tm[j] = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(tm[j] << 16);
+            tl[j] = bf16_rne(r2);
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ph[j] = th[2 * j] | (th[2 * j + 1] << 16);
+            pm[j] = tm[2 * j] | (tm[2 * j + 1] << 16);
+            pl[j] = tl[2 * j] | (tl[2 * j + 1] << 16);
+        }
+        *reinterpret_cast<u32x4 *>(sb + b_lds) = ph;
+        *reinterpret_cast<u32x4 *>(sb + b_lds + PLANE_B) = pm;
+        *reinterpret_cast<u32x4 *>(sb + b_lds + 2 * PLANE_B) = pl;
+    };
+
+    // ---- fragment addressing: lane -> row (lane & 31), K chunk (lane >> 5) -------------------------------
+    const int kg = lane >> 5;
+    int fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra_ = wm * 64 + t * 32 + (lane & 31);
+        fa[t] = ra_ * 32 + ((kg ^ ((ra_ >> 3) & 1)) << 4);
+        const int rb_ = wn * 64 + t * 32 + (lane & 31);
+        fb[t] = 3 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (threadIdx.x < CM) sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+    load(0);
+    store(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();                                   // stage kt visible; buffer cur ^ 1 free
+        load(kt + 1 < nk ? kt + 1 : kt);                   // branch-free: the last stage re-loads itself
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = sm + cur * STAGE;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[t][p] = *reinterpret_cast<const bf16x8 *>(sb + fa[t] + p * PLANE_A);
+                b[t][p] = *reinterpret_cast<const bf16x8 *>(sb + fb[t] + p * PLANE_B);
+            }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x16 c = acc[mi][ni];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        store(cur ^ 1);
+    }
+
+    // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
+    // pixel p0 + 64 wn + 32 ni + (lane & 31)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
+        if (pp >= total) continue;
+        const int64_t bimg = pp / hw, off = pp % hw;
+        float *yo = y + bimg * (int64_t)cout * hw + off;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[mi][ni][r] + sBias[ch - co0];
+                if (RELU_OUT) v = fmaxf(v, 0.f);
+                yo[(int64_t)ch * hw] = v;
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                             const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
+                             float *y, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (cin % KC || cout % CM) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
+    const size_t lds = 2 * (size_t)STAGE;
+#define MIRX_S3(P, R)                                                                                      \
+    {                                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_s3<P, R>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL((k_conv1x1_s3<P, R>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w3, bias, n, hw, \
+                           cout, y);                                                                       \
+    }
+    if (scale) {
+        if (relu_out) MIRX_S3(true, true) else MIRX_S3(true, false)
+    } else {
+        if (relu_out) MIRX_S3(false, true) else MIRX_S3(false, false)
+    }
+#undef MIRX_S3
+    return hipGetLastError();
+}
+
+}  // namespace mirx

@@ -103,7 +103,8 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
     return out
 
 
-def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hip_conv3x3=True):
+def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hip_conv3x3=True,
+                       split3_min_cin=0):
     """Inference path of one dense block (CUDA, eval):
        per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
@@ -114,14 +115,20 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
     buf[:, : block.cin] = x
     c = block.cin
     for name, layer in block.items():
-        sc1, sh1, w1, b1, ones, w1t, u3 = cache[name]
+        sc1, sh1, w1, b1, ones, w1t, u3, w3 = cache[name]
         if use_hip_conv1x1:
             # norm1 + relu1 + conv1 + norm2 + relu2 in ONE fp32-MFMA pass over the buffer prefix
             y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
             ev = _timer_start(timer)
-            _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1), _ptr(w1t),
-                                                _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
-                       "mirx_conv1x1_bn_relu")
+            if c >= split3_min_cin:
+                # many input channels: the fp32 MFMAs bound the layer -> three-bf16-term formulation
+                _lib.check(lib.mirx_conv1x1_bn_relu_split3(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1),
+                                                           _ptr(w3), _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y),
+                                                           _stream(x.device)), "mirx_conv1x1_bn_relu_split3")
+            else:
+                _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1), _ptr(w1t),
+                                                    _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
+                           "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
             if use_hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
                 # Winograd F(2x2,3x3) on fp32 MFMA, written straight into this layer's slice of the buffer
@@ -145,11 +152,11 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
     return buf
 
 
-def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None):
+def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_min_cin=0):
     """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
     the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
     lib = _lib.load()
-    sc, sh, wt = cache
+    sc, sh, wt, w3 = cache
     b, c, h, w = buf.shape
     if h % 2 or w % 2:
         return tr.pool(tr.conv(F.relu(F.batch_norm(buf, tr.norm.running_mean, tr.norm.running_var,
@@ -160,9 +167,14 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None):
     if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
         out = torch.empty((b, wt.shape[1], h // 2, w // 2), dtype=torch.float32, device=buf.device)
         ev = _timer_start(timer)
-        _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(wt), None, b,
-                                            (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out), _stream(buf.device)),
-                   "mirx_conv1x1_bn_relu")
+        if c >= split3_min_cin:
+            _lib.check(lib.mirx_conv1x1_bn_relu_split3(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(w3), None,
+                                                       b, (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out),
+                                                       _stream(buf.device)), "mirx_conv1x1_bn_relu_split3")
+        else:
+            _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(wt), None, b,
+                                                (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out), _stream(buf.device)),
+                       "mirx_conv1x1_bn_relu")
         _timer_stop(timer, ev, 2.0 * b * (h // 2) * (w // 2) * c * wt.shape[1])
         return out
     return F.conv2d(pooled, tr.conv.weight)
@@ -213,6 +225,18 @@ def _winograd_weights(w):
     return u.contiguous()
 
 
+def _split3_weights(w):
+    """[cout, cin] fp32 -> the three bf16 terms of every weight (w = h + m + l exactly, 3 x 8 mantissa
+    bits), laid out for mirx_conv1x1_bn_relu_split3: [cout // 128][cin // 16][3][128][16] bf16."""
+    w = w.detach().float()
+    h = w.to(torch.bfloat16)
+    m = (w - h.float()).to(torch.bfloat16)
+    lo = (w - h.float() - m.float()).to(torch.bfloat16)
+    cout, cin = w.shape
+    t = torch.stack([h, m, lo], 0).reshape(3, cout // 128, 128, cin // 16, 16)
+    return t.permute(1, 3, 0, 2, 4).contiguous()
+
+
 def _bn_affine(bn):
     """Eval-mode BatchNorm as y = x*scale + shift (fp32)."""
     scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -246,6 +270,8 @@ class DenseNet121(nn.Module):
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
         self.use_hip_stem = True
         self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
+        self.split3_min_cin = 0            # 1x1 convs with at least this many input channels use the 3-term bf16 kernel
+                                           # (measured faster than the fp32-MFMA kernel on every DenseNet-121 layer)
         self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
@@ -287,11 +313,13 @@ class DenseNet121(nn.Module):
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
                     w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
-                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t, _winograd_weights(layer.conv2.weight))
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t, _winograd_weights(layer.conv2.weight),
+                                  _split3_weights(w1.view(w1.shape[0], w1.shape[1])))
                 cache[name] = blk
             elif name.startswith("transition"):
                 wt = m.conv.weight.detach().float()
-                cache[name] = _bn_affine(m.norm) + (wt.view(wt.shape[0], wt.shape[1]).t().contiguous(),)
+                cache[name] = _bn_affine(m.norm) + (wt.view(wt.shape[0], wt.shape[1]).t().contiguous(),
+                                                    _split3_weights(wt.view(wt.shape[0], wt.shape[1])))
         cache["norm0"] = _bn_affine(f.norm0)
         cache["norm5"] = _bn_affine(f.norm5)
         self._infer_cache = cache
@@ -316,9 +344,9 @@ class DenseNet121(nn.Module):
         for name, m in f.named_children():
             if name.startswith("denseblock"):
                 x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer,
-                                       self.use_hip_conv3x3)
+                                       self.use_hip_conv3x3, self.split3_min_cin)
             elif name.startswith("transition"):
-                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer)
+                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer, self.split3_min_cin)
         return x
 
     def _head_fused(self, fmap, normalize):

@@ -189,3 +189,41 @@ def test_embeddings_at_other_resolutions(model_and_sd, size):
         y = m(x.cuda()).cpu()
         ref = OD.embed(x, sd)
     assert float((y - ref).abs().max()) <= 1e-5, float((y - ref).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw,n,prologue,relu", [(256, 128, 196, 3, True, True), (512, 128, 49, 5, True, True),
+                                                         (1024, 512, 49, 2, False, False), (64, 128, 3136, 1, True, True),
+                                                         (992, 128, 37, 3, True, True)])
+def test_split3_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu):
+    """mirx_conv1x1_bn_relu_split3 (three bf16 terms per operand, six MFMAs per product) against a float64
+    restatement of relu(W relu(bn(x)) + b): fp32-grade -- 3e-6 relative to the largest output, the same
+    bound the fp32-MFMA kernel meets."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _split3_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(cin + hw)
+    ctot = cin + 32
+    buf = torch.randn(n, ctot, hw, generator=g, device=dev)
+    w = torch.randn(cout, cin, generator=g, device=dev) / cin ** 0.5
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3
+    bias = torch.randn(cout, generator=g, device=dev)
+    w3 = _split3_weights(w)
+    assert w3.shape == (cout // 128, cin // 16, 3, 128, 16) and w3.dtype == torch.bfloat16
+    y = torch.empty(n, cout, hw, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    _lib.check(lib.mirx_conv1x1_bn_relu_split3(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
+                                               vp(sh) if prologue else None, vp(w3), vp(bias), n, hw, cout,
+                                               1 if relu else 0, vp(y), None), "split3")
+    torch.cuda.synchronize()
+    xin = buf[:, :cin].double()
+    if prologue:
+        xin = torch.relu(xin * sc.double()[None, :, None] + sh.double()[None, :, None])
+    want = torch.einsum("oc,bcp->bop", w.double(), xin) + bias.double()[None, :, None]
+    if relu:
+        want = torch.relu(want)
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
