@@ -224,10 +224,16 @@ def main():
         model.conv1x1_timer = None
         if ms > 0:
             ach = fl / (ms * 1e-3) / 1e12
-            embed_roof = {"bound": "mfma", "kernel": "mirx::k_conv1x1 (fused BN+ReLU+1x1 conv+BN+ReLU, fp32 MFMA), "
-                          f"{nl} launches of one {args.embed_batch}-image forward", "dtype": "f32",
-                          "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "flop_per_forward": fl, "ms_per_forward": ms,
+            # every product of this kernel is six bf16 MFMAs (three-term split of both fp32 operands), so its
+            # matrix-pipe roofline in fp32-equivalent FLOP is the dense bf16 peak / 6
+            split3 = getattr(model, "split3_min_cin", 1 << 30) <= 64
+            peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if split3 else MFMA_F32_PEAK_TFLOPS
+            kname = ("mirx::k_conv1x1_s3 (fused BN+ReLU+1x1 conv+BN+ReLU, 3-term bf16 MFMA, fp32-grade)" if split3
+                     else "mirx::k_conv1x1 (fused BN+ReLU+1x1 conv+BN+ReLU, fp32 MFMA)")
+            embed_roof = {"bound": "mfma", "kernel": f"{kname}, {nl} launches of one {args.embed_batch}-image forward",
+                          "dtype": "f32 (3 x bf16 terms)" if split3 else "f32",
+                          "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)",
+                          "frac": ach / peak, "flop_per_forward": fl, "ms_per_forward": ms,
                           "traffic": None}
     if rank == 0:
         dimp = (args.dim + 63) // 64 * 64

@@ -24,6 +24,8 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 constexpr int CM = 128;            // output channels per workgroup
 constexpr int CP = 128;            // pixels per workgroup
@@ -31,12 +33,6 @@ constexpr int KC = 16;             // channels per stage
 constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage (4 KiB)
 constexpr int PLANE_B = CP * KC * 2;
 constexpr int STAGE = 3 * PLANE_A + 3 * PLANE_B;   // 24 KiB
-
-__device__ inline unsigned bf16_rne(float f) {      // finite inputs
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
-}
 
 template <bool PROLOGUE, bool RELU_OUT>
 __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__ x, int64_t xbs, int cin,
@@ -95,23 +91,24 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
         char *sb = sm + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4 *>(sb + a_lds[i]) = ra[i];
-        unsigned th[8], tm[8], tl[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = rb[j];
-            if (PROLOGUE) v = fmaxf(fmaf(v, rsc[j], rsh[j]), 0.f);
-            th[j] = bf16_rne(v);
-            const float r1 = v - __uint_as_float(th[j] << 16);
-            tm[j] = bf16_rne(r1);
-            const float r2 = r1 - __uint_as_float(tm[j] << 16);
-            tl[j] = bf16_rne(r2);
-        }
+        // three bf16 terms of each value, two values at a time: fptrunc <2 x float> -> <2 x bfloat> is one
+        // v_cvt_pk_bf16_f32 (round to nearest even) on gfx950
         u32x4 ph, pm, pl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ph[j] = th[2 * j] | (th[2 * j + 1] << 16);
-            pm[j] = tm[2 * j] | (tm[2 * j + 1] << 16);
-            pl[j] = tl[2 * j] | (tl[2 * j + 1] << 16);
+            f32x2 v = {rb[2 * j], rb[2 * j + 1]};
+            if (PROLOGUE) {
+                v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
+                v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
+            }
+            const bf16x2 h = __builtin_convertvector(v, bf16x2);
+            const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+            const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+            const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+            const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+            ph[j] = __builtin_bit_cast(unsigned, h);
+            pm[j] = __builtin_bit_cast(unsigned, m);
+            pl[j] = __builtin_bit_cast(unsigned, l);
         }
         *reinterpret_cast<u32x4 *>(sb + b_lds) = ph;
         *reinterpret_cast<u32x4 *>(sb + b_lds + PLANE_B) = pm;
