@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w3,
                                                        const float *__restrict__ bias, int64_t n, int hw, int cout,
-                                                       float *__restrict__ y) {
+                                                       float *__restrict__ y, int64_t ybs) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ float sBias[CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
         const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
         if (pp >= total) continue;
         const int64_t bimg = pp / hw, off = pp % hw;
-        float *yo = y + bimg * (int64_t)cout * hw + off;
+        float *yo = y + bimg * ybs + off;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
 
 hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
-                             float *y, hipStream_t st) {
+                             float *y, int64_t ybs, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
@@ -203,7 +203,7 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
         hipLaunchKernelGGL((k_conv1x1_s3<P, R>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w3, bias, n, hw, \
-                           cout, y);                                                                       \
+                           cout, y, ybs);                                                                       \
     }
     if (scale) {
         if (relu_out) MIRX_S3(true, true) else MIRX_S3(true, false)

@@ -633,15 +633,16 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
 
 int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin, const float *scale1_or_null,
                                 const float *shift1_or_null, const void *w3, const float *bias_or_null, int64_t n,
-                                int hw, int cout, int relu_out, float *y, void *stream) {
+                                int hw, int cout, int relu_out, float *y, int64_t y_batch_stride, void *stream) {
     MIRX_CHECK(n >= 0 && hw >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0,
                "conv1x1_split3: cin must be a multiple of 16 and cout of 128");
     MIRX_CHECK((scale1_or_null == nullptr) == (shift1_or_null == nullptr), "conv1x1_split3: scale and shift go together");
     MIRX_CHECK(n == 0 || (x && w3 && y), "conv1x1_split3: null buffer");
     MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1_split3: batch stride smaller than the channel prefix");
+    MIRX_CHECK(y_batch_stride >= (int64_t)cout * hw, "conv1x1_split3: output batch stride smaller than cout * hw");
     MIRX_HIP(launch_conv1x1_s3(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
                                reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, hw, cout, relu_out, y,
-                               reinterpret_cast<hipStream_t>(stream)));
+                               y_batch_stride, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

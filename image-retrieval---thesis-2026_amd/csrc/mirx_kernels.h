@@ -57,7 +57,7 @@ hipError_t launch_topk_merge(const double *in_scores, const int64_t *in_ids, int
 // ---- k_conv1x1_s3.hip --------------------------------------------------------------------
 hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
-                             float *y, hipStream_t st);
+                             float *y, int64_t ybs, hipStream_t st);
 
 // ---- k_conv3x3.hip ----------------------------------------------------------------------
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,

@@ -110,9 +110,14 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
        into the block buffer."""
     lib = _lib.load()
-    b, _, h, w = x.shape
-    buf = torch.empty((b, block.cout, h, w), dtype=torch.float32, device=x.device)
-    buf[:, : block.cin] = x
+    if isinstance(x, tuple):           # (block buffer, channels already in place): the transition wrote them there
+        buf = x[0]
+        x = buf
+        b, _, h, w = buf.shape
+    else:
+        b, _, h, w = x.shape
+        buf = torch.empty((b, block.cout, h, w), dtype=torch.float32, device=x.device)
+        buf[:, : block.cin] = x
     c = block.cin
     for name, layer in block.items():
         sc1, sh1, w1, b1, ones, w1t, u3, w3 = cache[name]
@@ -121,10 +126,11 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
             y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
             ev = _timer_start(timer)
             if c >= split3_min_cin:
-                # many input channels: the fp32 MFMAs bound the layer -> three-bf16-term formulation
+                # three-bf16-term MFMA formulation (fp32-grade, faster than the fp32-MFMA kernel on every layer)
                 _lib.check(lib.mirx_conv1x1_bn_relu_split3(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1),
                                                            _ptr(w3), _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y),
-                                                           _stream(x.device)), "mirx_conv1x1_bn_relu_split3")
+                                                           w1t.shape[1] * h * w, _stream(x.device)),
+                           "mirx_conv1x1_bn_relu_split3")
             else:
                 _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1), _ptr(w1t),
                                                     _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
@@ -152,7 +158,7 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
     return buf
 
 
-def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_min_cin=0):
+def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_min_cin=0, next_channels=None):
     """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
     the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
     lib = _lib.load()
@@ -165,13 +171,19 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
     _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled),
                                          _stream(buf.device)), "mirx_bn_relu_avgpool2")
     if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
-        out = torch.empty((b, wt.shape[1], h // 2, w // 2), dtype=torch.float32, device=buf.device)
         ev = _timer_start(timer)
         if c >= split3_min_cin:
+            # written straight into the channel prefix of the NEXT dense block's buffer when its width is known
+            ctot = next_channels if next_channels else wt.shape[1]
+            out = torch.empty((b, ctot, h // 2, w // 2), dtype=torch.float32, device=buf.device)
             _lib.check(lib.mirx_conv1x1_bn_relu_split3(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(w3), None,
                                                        b, (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out),
-                                                       _stream(buf.device)), "mirx_conv1x1_bn_relu_split3")
+                                                       ctot * (h // 2) * (w // 2), _stream(buf.device)),
+                       "mirx_conv1x1_bn_relu_split3")
+            _timer_stop(timer, ev, 2.0 * b * (h // 2) * (w // 2) * c * wt.shape[1])
+            return (out, wt.shape[1]) if next_channels else out
         else:
+            out = torch.empty((b, wt.shape[1], h // 2, w // 2), dtype=torch.float32, device=buf.device)
             _lib.check(lib.mirx_conv1x1_bn_relu(_ptr(pooled), c * (h // 2) * (w // 2), c, None, None, _ptr(wt), None, b,
                                                 (h // 2) * (w // 2), wt.shape[1], 0, _ptr(out), _stream(buf.device)),
                        "mirx_conv1x1_bn_relu")
@@ -341,12 +353,15 @@ class DenseNet121(nn.Module):
             x = y
         else:
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))
-        for name, m in f.named_children():
+        children = list(f.named_children())
+        for i, (name, m) in enumerate(children):
             if name.startswith("denseblock"):
                 x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer,
                                        self.use_hip_conv3x3, self.split3_min_cin)
             elif name.startswith("transition"):
-                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer, self.split3_min_cin)
+                nxt = children[i + 1][1] if i + 1 < len(children) and children[i + 1][0].startswith("denseblock") else None
+                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer, self.split3_min_cin,
+                                      nxt.cout if nxt is not None else None)
         return x
 
     def _head_fused(self, fmap, normalize):

@@ -161,12 +161,15 @@ int mirx_topk_merge(const double *in_scores, const int64_t *in_ids, int nshard, 
  * MFMAs per product block, fp32 accumulation): fp32-grade results at 2.67x less matrix-pipe time, for
  * the layers with many input channels.  Same arguments as mirx_conv1x1_bn_relu except the weights:
  * w3 = device bf16 [cout / 128][cin / 16][3][128][16], the three terms of W[co, k] (already multiplied
- * by the folded norm2 scale) for output block co / 128 and input stage k / 16 (mirx.model._split3_weights).
+ * by the folded norm2 scale) for output block co / 128 and input stage k / 16 (mirx.model._split3_weights),
+ * and the output batch stride: image b is written at y + b * y_batch_stride as [cout, hw] (cout * hw for a
+ * packed tensor; the channel-prefix of the next dense block's buffer for a transition).
  * cin % 16 == 0, cout % 128 == 0; any hw.
  */
 int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin, const float *scale1_or_null,
                                 const float *shift1_or_null, const void *w3, const float *bias_or_null,
-                                int64_t n, int hw, int cout, int relu_out, float *y, void *stream);
+                                int64_t n, int hw, int cout, int relu_out, float *y, int64_t y_batch_stride,
+                                void *stream);
 
 /*
  * 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1, no bias): conv2 of

@@ -213,11 +213,12 @@ def test_split3_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu):
     bias = torch.randn(cout, generator=g, device=dev)
     w3 = _split3_weights(w)
     assert w3.shape == (cout // 128, cin // 16, 3, 128, 16) and w3.dtype == torch.bfloat16
-    y = torch.empty(n, cout, hw, device=dev)
+    ybuf = torch.full((n, cout + 8, hw), -5.0, device=dev)          # written as a channel prefix of a wider buffer
+    y = ybuf[:, :cout]
     vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
     _lib.check(lib.mirx_conv1x1_bn_relu_split3(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
                                                vp(sh) if prologue else None, vp(w3), vp(bias), n, hw, cout,
-                                               1 if relu else 0, vp(y), None), "split3")
+                                               1 if relu else 0, vp(y), (cout + 8) * hw, None), "split3")
     torch.cuda.synchronize()
     xin = buf[:, :cin].double()
     if prologue:
@@ -227,3 +228,4 @@ def test_split3_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu):
         want = torch.relu(want)
     err = float((y.double() - want).abs().max())
     assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+    assert bool((ybuf[:, cout:] == -5.0).all())
