@@ -51,7 +51,13 @@ constexpr int A_TILE_BYTES = BM * ROW_BYTES;  // 32 KiB
 #ifdef MIRX_EXP_NOBAR   // no workgroup barrier in the K loop
 #define MIRX_KBARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
-#define MIRX_KBARRIER() __syncthreads()
+// vmcnt(0) first: a K-tile is published only after this wave's `buffer_load ... lds` pieces have landed (the
+// compiler's own wait before s_barrier covers registers, not the asynchronous LDS writes)
+#define MIRX_KBARRIER()                                      \
+    do {                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+        __syncthreads();                                     \
+    } while (0)
 #endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
 
     stage_tile<BM>(smem, rsrc_a, voff_a, 0, pstride_a, wave);
     stage_tile<BN>(smem + LDS_B0, rsrc_b, voff_b, 0, pstride_b, wave);
-    __syncthreads();                                   // K-tile 0 visible (and lcnt zeroed)
+    MIRX_KBARRIER();                                   // K-tile 0 visible (and lcnt zeroed)
     stage_tile<BM>(smem + A_TILE_BYTES, rsrc_a, voff_a, ROW_BYTES, pstride_a, wave);
     stage_tile<BN>(smem + LDS_B0 + B_TILE_BYTES, rsrc_b, voff_b, ROW_BYTES, pstride_b, wave);
 #pragma unroll
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 
     stage_tile<BM>(smem, rsrc_a, voff_a, 0, pstride_a, wave);
     stage_tile<BN>(smem + LDS_B0, rsrc_b, voff_b, 0, pstride_b, wave);
-    __syncthreads();
+    MIRX_KBARRIER();
     stage_tile<BM>(smem + A_TILE_BYTES, rsrc_a, voff_a, ROW_BYTES, pstride_a, wave);
     stage_tile<BN>(smem + LDS_B0 + B_TILE_BYTES, rsrc_b, voff_b, ROW_BYTES, pstride_b, wave);
 #pragma unroll

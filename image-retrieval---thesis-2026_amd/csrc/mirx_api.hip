@@ -646,6 +646,19 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
     return MIRX_OK;
 }
 
+int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
+                       const float *residual_or_null, const float *gamma_or_null, float *y, void *stream) {
+    MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 128 && n % 128 == 0,
+               "linear_split3: k must be a multiple of 16 and n of 128");
+    MIRX_CHECK(act == 0 || act == 1, "linear_split3: act is 0 (none) or 1 (gelu)");
+    MIRX_CHECK(m == 0 || (x && w3 && y), "linear_split3: null buffer");
+    MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split3: gamma scales the residual branch only");
+    MIRX_CHECK(x != y, "linear_split3: y may alias the residual, not the input");
+    MIRX_HIP(launch_linear_s3(x, m, k, reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, act, residual_or_null,
+                              gamma_or_null, y, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_batch_stride,
                                void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3: batch must be in [0, 65535]");

@@ -59,6 +59,10 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
                              const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
                              float *y, int64_t ybs, hipStream_t st);
 
+// ---- k_linear_s3.hip ---------------------------------------------------------------------
+hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,
+                            const float *res, const float *gamma, float *y, hipStream_t st);
+
 // ---- k_conv3x3.hip ----------------------------------------------------------------------
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
                                hipStream_t st);

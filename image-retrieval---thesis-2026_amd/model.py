@@ -264,6 +264,38 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
+
+
+def _linear_s3_ok(mod, x):
+    return (SPLIT3_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and mod.in_features % 16 == 0 and mod.out_features % 128 == 0)
+
+
+def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
+    """[HIP] y = epi(x W^T + b) through mirx_linear_split3 (include/mirx.h); x: [..., k] fp32 CUDA.
+    act=1: GELU; res/gamma: y = res + gamma * v (may be written in place with out=res)."""
+    w = mod.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cached = getattr(mod, "_mirx_w3", None)
+    if cached is None or cached[0] != key:
+        cached = (key, _split3_weights(w.detach()))
+        mod._mirx_w3 = cached
+    x = x.contiguous()
+    m = x.numel() // mod.in_features
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (mod.out_features,), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == out.shape
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mirx_linear_split3(_ptr(x), m, mod.in_features, _ptr(cached[1]),
+                                                  _ptr(mod.bias.detach()) if mod.bias is not None else None,
+                                                  mod.out_features, act, _ptr(res) if res is not None else None,
+                                                  _ptr(gamma.detach()) if gamma is not None else None, _ptr(out),
+                                                  _stream(x.device)), "mirx_linear_split3")
+    return out
+
+
 class DenseNet121(nn.Module):
     """Reference model.py:42-84, MI355X-native inference path."""
 
@@ -436,6 +468,8 @@ class _CnxMlp(nn.Module):
         self.fc2 = nn.Linear(4 * dim, dim)
 
     def forward(self, x):
+        if _linear_s3_ok(self.fc1, x) and _linear_s3_ok(self.fc2, x):
+            return _linear_s3(self.fc2, self.grn(_linear_s3(self.fc1, x, act=1)))      # bias + GELU in the epilogue
         return self.fc2(self.grn(self.act(self.fc1(x))))
 
 
@@ -598,6 +632,21 @@ class _VitBlock(nn.Module):
         self.ls2 = _LayerScale(dim)
 
     def forward(self, x):
+        at = self.attn
+        if (x.dim() == 3 and x.shape[-1] // at.num_heads == 64 and _linear_s3_ok(at.qkv, x)
+                and _linear_s3_ok(at.proj, x) and _linear_s3_ok(self.mlp.fc1, x) and _linear_s3_ok(self.mlp.fc2, x)):
+            # MI355X inference path: 4 split-3 MFMA Linear launches (bias / GELU / LayerScale + skip in their
+            # epilogues) + the flash-attention kernel + 2 LayerNorms per block
+            b, n, c = x.shape
+            x = x.contiguous()
+            qkv = _linear_s3(at.qkv, self.norm1(x))
+            a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a),
+                                                              _stream(x.device)), "mirx_attention_qkv_f32")
+            x = _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma)
+            hid = _linear_s3(self.mlp.fc1, self.norm2(x), act=1)
+            return _linear_s3(self.mlp.fc2, hid, res=x, gamma=self.ls2.gamma, out=x)
         x = x + self.ls1(self.attn(self.norm1(x)))
         return x + self.ls2(self.mlp(self.norm2(x)))
 

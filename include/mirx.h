@@ -172,6 +172,20 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
                                 void *stream);
 
 /*
+ * Linear layer of the token-major backbones (replaces the nn.Linear calls inside the timm / transformers
+ * models the reference instantiates: model.py:448-494 DinoV2, model.py:87-118 ConvNeXtV2,
+ * model.py:536-638 MedSigLIP vision tower), fp32-grade on the bf16 matrix pipe with three bf16 terms per operand:
+ *     y[i, j] = epi( sum_k x[i, k] W[j, k] + bias[j] )
+ *     act = 1: exact (erf) GELU;  residual != NULL:  y = residual + gamma[j] * v  (LayerScale + skip; gamma
+ *     NULL = 1; y may alias residual).
+ * x = device fp32 [m, k] row-major; w3 = device bf16 [n / 128][k / 16][3][128][16] (the layout of
+ * mirx_conv1x1_bn_relu_split3, mirx.model._split3_weights(W)); y = device fp32 [m, n].
+ * k % 16 == 0, n % 128 == 0, any m >= 0.
+ */
+int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
+                       const float *residual_or_null, const float *gamma_or_null, float *y, void *stream);
+
+/*
  * 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1, no bias): conv2 of
  * torchvision's _DenseLayer (model.py:53), as Winograd F(2x2,3x3) on fp32 MFMA.  x: device NCHW fp32
  * [n, 128, side, side] (packed), side = 56, 28, 14 or 7.  u: device fp32 [16 stages][16][8][32] = the

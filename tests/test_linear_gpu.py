@@ -1,0 +1,85 @@
+"""mirx_linear_split3 (csrc/k_linear_s3.hip): the token-major Linear layer on three-term bf16 MFMA, against
+a float64 restatement of  y = epi(x W^T + b).  Tolerance: 3e-6 of the largest |y| (the dropped cross
+terms are <= 3 * 2^-24 per product; accumulation is fp32) -- the class of an fp32 GEMM."""
+import ctypes
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ref(x, w, b, act, res, gamma):
+    v = x.double() @ w.double().t()
+    if b is not None:
+        v = v + b.double()
+    if act:
+        v = 0.5 * v * (1.0 + torch.erf(v / math.sqrt(2.0)))
+    if res is not None:
+        v = res.double() + (gamma.double() if gamma is not None else 1.0) * v
+    return v
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 16, 128), (127, 768, 768), (300, 768, 2304), (1370 * 2 + 5, 3072, 768),
+                                   (4096, 128, 512), (129, 1152, 4352), (200, 48, 128), (64, 80, 256), (33, 32, 128)])
+@pytest.mark.parametrize("act,use_res,use_gamma,use_bias", [(0, False, False, True), (1, False, False, True),
+                                                            (0, True, True, True), (1, True, False, False)])
+def test_linear_split3_matches_float64(m, k, n, act, use_res, use_gamma, use_bias):
+    from mirx import _lib
+    from mirx.model import _split3_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(m * 7 + k + n + act)
+    x = (torch.randn(m, k, generator=g) * 1.5).to(dev)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(dev)
+    b = torch.randn(n, generator=g).to(dev) if use_bias else None
+    res = torch.randn(m, n, generator=g).to(dev) if use_res else None
+    gamma = torch.randn(n, generator=g).to(dev) if use_gamma else None
+    want = _ref(x, w, b, act, res, gamma)
+    w3 = _split3_weights(w)
+    y = res.clone() if use_res else torch.full((m, n), float("nan"), device=dev)     # in place over the residual
+    _lib.check(lib.mirx_linear_split3(_vp(x), m, k, _vp(w3), _vp(b), n, act, _vp(y) if use_res else None, _vp(gamma),
+                                      _vp(y), None), "mirx_linear_split3")
+    torch.cuda.synchronize()
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+
+
+def test_linear_split3_argument_checks():
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    x = torch.zeros(4, 24, device=dev)
+    y = torch.zeros(4, 128, device=dev)
+    w = torch.zeros(128 * 24 * 3, dtype=torch.bfloat16, device=dev)
+    assert lib.mirx_linear_split3(_vp(x), 4, 24, _vp(w), None, 128, 0, None, None, _vp(y), None) != 0   # k % 16
+    assert lib.mirx_linear_split3(_vp(x), 4, 16, _vp(w), None, 100, 0, None, None, _vp(y), None) != 0   # n % 128
+    assert lib.mirx_linear_split3(_vp(x), 4, 16, _vp(w), None, 128, 2, None, None, _vp(y), None) != 0   # act
+    assert lib.mirx_linear_split3(_vp(x), 0, 16, _vp(w), None, 128, 0, None, None, _vp(y), None) == 0   # empty batch
+
+
+def test_vit_block_split3_matches_rocblas_path():
+    """The fused block path (4 split-3 Linear launches + attention kernel) against the module-by-module
+    rocBLAS fp32 path of the same block."""
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = mm._VitBlock(768, 12).to(dev).eval()
+    with torch.no_grad():
+        blk.ls1.gamma.normal_()
+        blk.ls2.gamma.normal_()
+        for p in (blk.attn.qkv.bias, blk.attn.proj.bias, blk.mlp.fc1.bias, blk.mlp.fc2.bias):
+            p.normal_(std=0.1)
+        x = torch.randn(3, 257, 768, device=dev)
+        got = blk(x)
+        mm.SPLIT3_LINEAR = False
+        try:
+            want = blk(x)
+        finally:
+            mm.SPLIT3_LINEAR = True
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
