@@ -68,6 +68,52 @@ __global__ __launch_bounds__(256) void k_dwconv7(const float *__restrict__ x, co
     }
 }
 
+// Global response normalisation (timm GlobalResponseNorm, channels last), split in two HBM passes instead of
+// PyTorch's eight: (1) gx[b][c] = || x[b, :, :, c] ||_2, (2) x = x * scale[b][c] + shift[c] in place, with
+// scale = 1 + weight * gx / (mean_c gx + eps) computed by the caller on the tiny [n][c] tensor.
+// Norm: workgroup = (image, 64 channels); lanes walk channels (256-byte rows), the 4 waves take every 4th
+// position; fixed summation order -> bit-reproducible.
+__global__ __launch_bounds__(256) void k_grn_norm(const float *__restrict__ x, int hw, int c, float *__restrict__ gx) {
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 64 + lane;
+    const int64_t img = blockIdx.y;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < c) {
+        const float *p = x + img * hw * (int64_t)c + c0;
+        int pos = wave;
+        for (; pos + 12 < hw; pos += 16) {               // four independent chains per lane
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = p[(int64_t)(pos + 4 * u) * c];
+                acc[u] = fmaf(v, v, acc[u]);
+            }
+        }
+        for (; pos < hw; pos += 4) {
+            const float v = p[(int64_t)pos * c];
+            acc[0] = fmaf(v, v, acc[0]);
+        }
+    }
+    part[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (wave == 0 && c0 < c) gx[img * c + c0] = sqrtf((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+
+__global__ __launch_bounds__(256) void k_grn_apply(float *__restrict__ x, int64_t total4, int hw, int c4,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int cc = (int)(i % c4);
+        const int64_t img = i / ((int64_t)hw * c4);
+        f32x4 v = reinterpret_cast<f32x4 *>(x)[i];
+        const f32x4 sc = reinterpret_cast<const f32x4 *>(scale)[img * c4 + cc];
+        const f32x4 sh = reinterpret_cast<const f32x4 *>(shift)[cc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+        reinterpret_cast<f32x4 *>(x)[i] = v;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
@@ -78,6 +124,23 @@ hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int
     if (n > 65535 || (c + DCH - 1) / DCH > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_dwconv7, dim3((unsigned)tiles, (unsigned)((c + DCH - 1) / DCH), (unsigned)n), dim3(256), lds,
                        st, x, w, bias, c, h, wd, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_grn_norm(const float *x, int64_t n, int hw, int c, float *gx, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_grn_norm, dim3((unsigned)((c + 63) / 64), (unsigned)n), dim3(256), 0, st, x, hw, c, gx);
+    return hipGetLastError();
+}
+
+hipError_t launch_grn_apply(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (c % 4) return hipErrorInvalidValue;
+    const int64_t total4 = n * hw * (int64_t)(c / 4);
+    const int64_t blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(k_grn_apply, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, x, total4, hw,
+                       c / 4, scale, shift);
     return hipGetLastError();
 }
 

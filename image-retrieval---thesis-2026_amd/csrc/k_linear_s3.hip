@@ -7,6 +7,9 @@
 //   w3  [n / 128][k / 16][3 terms][128][16] bf16              -> MFMA column operand (mirx.model._split3_weights)
 //   y   [m][n] fp32:  v = acc + bias[n];  ACT == 1: v = gelu(v) (erf form);
 //                     RES: v = res[m][n] + gamma[n] * v  (LayerScale + residual; y may alias res)
+//   NCHW variant (ConvNeXt block tail): token t = image t / tpi, pixel t % tpi; y and res are [image][n][tpi].
+//   The MFMA operand roles are swapped (rows = outputs, lanes = tokens) so that a half-wave still stores 128
+//   contiguous bytes.
 //
 // Workgroup tile 128 tokens x 128 outputs, 4 waves (2 x 2, 64 x 64 each), 16 features per stage,
 // double-buffered LDS (48 KiB, 3 workgroups per CU).  The weights go global -> LDS by DMA (no registers); the
@@ -41,12 +44,12 @@ constexpr int KC = 16;             // features per stage
 constexpr int PLANE = 128 * KC * 2;            // bytes of one term of one operand stage (4 KiB)
 constexpr int STAGE = 6 * PLANE;               // x terms [0, 3), w terms [3, 6): 24 KiB
 
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool NCHW>
 __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ x, int64_t m, int k,
                                                       const uint16_t *__restrict__ w3,
                                                       const float *__restrict__ bias, int n, const float *res,
                                                       const float *__restrict__ gamma, float *y, int ntn,
-                                                      int64_t total_tiles, int64_t per_xcd) {
+                                                      int64_t total_tiles, int64_t per_xcd, int tpi) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= total_tiles) return;
@@ -137,13 +140,17 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 f32x16 c = acc[mi][ni];
-                // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                // smallest terms first; NCHW: outputs on the MFMA rows, tokens on the lanes
+#define MIRX_L3_MFMA(TA, TB)                                                                               \
+    c = NCHW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni][TB], a[mi][TA], c, 0, 0, 0)                   \
+             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA], b[ni][TB], c, 0, 0, 0);
+                MIRX_L3_MFMA(1, 1)
+                MIRX_L3_MFMA(2, 0)
+                MIRX_L3_MFMA(0, 2)
+                MIRX_L3_MFMA(1, 0)
+                MIRX_L3_MFMA(0, 1)
+                MIRX_L3_MFMA(0, 0)
+#undef MIRX_L3_MFMA
                 acc[mi][ni] = c;
             }
     };
@@ -178,6 +185,29 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
         mfma_stage(0);
     }
 
+    if (NCHW) {
+        // register r of tile (mi, ni) = output n0 + 64 wn + 32 ni + (r&3) + 8 (r>>2) + 4 (lane>>5), token
+        // m0 + 64 wm + 32 mi + (lane & 31): a half-wave stores 32 consecutive pixels of one output plane
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int64_t tok = m0 + wm * 64 + 32 * mi + (lane & 31);
+            if (tok >= m) continue;
+            const int64_t img = tok / tpi;
+            const int64_t base = img * n * tpi + (tok - img * tpi);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[mi][ni][r] + (bias ? bias[col] : 0.f);
+                    if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    const int64_t idx = base + (int64_t)col * tpi;
+                    if (RES) v = res[idx] + ((RES && gamma) ? gamma[col] : 1.f) * v;
+                    y[idx] = v;
+                }
+        }
+        return;
+    }
     // epilogue: register r of tile (mi, ni) = token m0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // output n0 + 64 wn + 32 ni + (lane & 31): a half-wave stores 128 contiguous bytes of one token row
 #pragma unroll
@@ -202,27 +232,30 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 }  // namespace
 
 hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,
-                            const float *res, const float *gamma, float *y, hipStream_t st) {
+                            const float *res, const float *gamma, float *y, int tokens_per_image, hipStream_t st) {
     if (m <= 0) return hipSuccess;
-    if (k % KC || n % TN || act < 0 || act > 1) return hipErrorInvalidValue;
+    if (k % KC || n % TN || act < 0 || act > 1 || tokens_per_image < 0) return hipErrorInvalidValue;
     const int ntn = n / TN;
     const int64_t total = ((m + TM - 1) / TM) * ntn;
     const int64_t per_xcd = (total + 7) / 8;
     if (per_xcd * 8 > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(per_xcd * 8));
     const size_t lds = 2 * (size_t)STAGE;
-#define MIRX_L3(A, R)                                                                                      \
+#define MIRX_L3(A, R, C)                                                                                   \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_s3<A, R>),              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_s3<A, R, C>),           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_linear_s3<A, R>), grid, dim3(256), lds, st, x, m, k, w3, bias, n, res, gamma, y, ntn, \
-                           total, per_xcd);                                                                \
+        hipLaunchKernelGGL((k_linear_s3<A, R, C>), grid, dim3(256), lds, st, x, m, k, w3, bias, n, res, gamma, y, \
+                           ntn, total, per_xcd, tokens_per_image);                                         \
     }
-    if (res) {
-        if (act) MIRX_L3(1, true) else MIRX_L3(0, true)
+    if (tokens_per_image > 0) {                       // ConvNeXt block tail: no activation variant needed
+        if (act) return hipErrorInvalidValue;
+        if (res) MIRX_L3(0, true, true) else MIRX_L3(0, false, true)
+    } else if (res) {
+        if (act) MIRX_L3(1, true, false) else MIRX_L3(0, true, false)
     } else {
-        if (act) MIRX_L3(1, false) else MIRX_L3(0, false)
+        if (act) MIRX_L3(1, false, false) else MIRX_L3(0, false, false)
     }
 #undef MIRX_L3
     return hipGetLastError();

@@ -655,7 +655,31 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
     MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split3: gamma scales the residual branch only");
     MIRX_CHECK(x != y, "linear_split3: y may alias the residual, not the input");
     MIRX_HIP(launch_linear_s3(x, m, k, reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, act, residual_or_null,
-                              gamma_or_null, y, reinterpret_cast<hipStream_t>(stream)));
+                              gamma_or_null, y, 0, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
+                            const float *bias_or_null, int n, const float *residual_or_null, float *y, void *stream) {
+    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 128 && n % 128 == 0,
+               "linear_split3_nchw: k must be a multiple of 16 and n of 128");
+    MIRX_CHECK(n_img == 0 || (x && w3 && y), "linear_split3_nchw: null buffer");
+    MIRX_CHECK(x != y, "linear_split3_nchw: y may alias the residual, not the input");
+    MIRX_HIP(launch_linear_s3(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, 0,
+                              residual_or_null, nullptr, y, tokens_per_image, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_grn_norm_nhwc(const float *x, int64_t n, int hw, int c, float *gx, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && hw >= 1 && c >= 1 && (n == 0 || (x && gx)), "grn_norm: bad argument");
+    MIRX_HIP(launch_grn_norm(x, n, hw, c, gx, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream) {
+    MIRX_CHECK(n >= 0 && hw >= 1 && c >= 4 && c % 4 == 0 && (n == 0 || (x && scale && shift)),
+               "grn_apply: c must be a multiple of 4");
+    MIRX_HIP(launch_grn_apply(x, n, hw, c, scale, shift, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

@@ -34,6 +34,10 @@ hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *sca
 // ---- k_convnext.hip ---------------------------------------------------------------------
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
                           float *y, hipStream_t st);
+// gx[b][c] = sqrt(sum over the hw positions of x[b][p][c]^2)       (x = [n][hw][c], channels last)
+hipError_t launch_grn_norm(const float *x, int64_t n, int hw, int c, float *gx, hipStream_t st);
+// x[b][p][c] = x[b][p][c] * scale[b][c] + shift[c], in place
+hipError_t launch_grn_apply(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, hipStream_t st);
 
 // ---- k_exact.hip ------------------------------------------------------------------------
 // out[i*ld + j] = fp64 ranking score of query qlist[i] (or i when qlist == null) vs row j.
@@ -60,8 +64,9 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
                              float *y, int64_t ybs, hipStream_t st);
 
 // ---- k_linear_s3.hip ---------------------------------------------------------------------
+// tokens_per_image == 0: y / res are [m][n]; > 0: token t is pixel t % tpi of image t / tpi and y / res are NCHW
 hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,
-                            const float *res, const float *gamma, float *y, hipStream_t st);
+                            const float *res, const float *gamma, float *y, int tokens_per_image, hipStream_t st);
 
 // ---- k_conv3x3.hip ----------------------------------------------------------------------
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,

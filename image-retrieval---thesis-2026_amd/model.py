@@ -272,15 +272,21 @@ def _linear_s3_ok(mod, x):
             and mod.in_features % 16 == 0 and mod.out_features % 128 == 0)
 
 
-def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
-    """[HIP] y = epi(x W^T + b) through mirx_linear_split3 (include/mirx.h); x: [..., k] fp32 CUDA.
-    act=1: GELU; res/gamma: y = res + gamma * v (may be written in place with out=res)."""
+def _linear_w3(mod):
+    """The three-term bf16 image of a Linear's weight, rebuilt when the parameter changes."""
     w = mod.weight
     key = (w.data_ptr(), w._version, w.device)
     cached = getattr(mod, "_mirx_w3", None)
     if cached is None or cached[0] != key:
         cached = (key, _split3_weights(w.detach()))
         mod._mirx_w3 = cached
+    return cached[1]
+
+
+def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
+    """[HIP] y = epi(x W^T + b) through mirx_linear_split3 (include/mirx.h); x: [..., k] fp32 CUDA.
+    act=1: GELU; res/gamma: y = res + gamma * v (may be written in place with out=res)."""
+    w3 = _linear_w3(mod)
     x = x.contiguous()
     m = x.numel() // mod.in_features
     if out is None:
@@ -288,7 +294,7 @@ def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mirx_linear_split3(_ptr(x), m, mod.in_features, _ptr(cached[1]),
+        _lib.check(_lib.load().mirx_linear_split3(_ptr(x), m, mod.in_features, _ptr(w3),
                                                   _ptr(mod.bias.detach()) if mod.bias is not None else None,
                                                   mod.out_features, act, _ptr(res) if res is not None else None,
                                                   _ptr(gamma.detach()) if gamma is not None else None, _ptr(out),
@@ -493,6 +499,28 @@ class _CnxBlock(nn.Module):
                                                            _ptr(y), _stream(x.device)), "mirx_dwconv7x7")
         else:
             y = self.conv_dw(x).permute(0, 2, 3, 1)
+        mlp = self.mlp
+        if (x.is_cuda and y.is_contiguous() and x.shape[0] <= 65535 and _linear_s3_ok(mlp.fc1, y)
+                and _linear_s3_ok(mlp.fc2, y)):
+            # MI355X path: fc1 + GELU in one MFMA launch, GRN as two HBM passes (norm, in-place apply), fc2
+            # written back NCHW with the skip added in its epilogue
+            lib = _lib.load()
+            b, c, h, w = x.shape
+            hid = _linear_s3(mlp.fc1, self.norm(y), act=1)                 # [b, h, w, 4c]
+            c4 = hid.shape[-1]
+            gx = torch.empty((b, c4), dtype=torch.float32, device=x.device)
+            out = torch.empty_like(xc)
+            with torch.cuda.device(x.device):
+                st = _stream(x.device)
+                _lib.check(lib.mirx_grn_norm_nhwc(_ptr(hid), b, h * w, c4, _ptr(gx), st), "mirx_grn_norm_nhwc")
+                scale = torch.addcmul(torch.ones_like(gx), mlp.grn.weight.detach(),
+                                      gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
+                _lib.check(lib.mirx_grn_apply_nhwc(_ptr(hid), b, h * w, c4, _ptr(scale),
+                                                   _ptr(mlp.grn.bias.detach()), st), "mirx_grn_apply_nhwc")
+                _lib.check(lib.mirx_linear_split3_nchw(_ptr(hid), b, h * w, c4, _ptr(_linear_w3(mlp.fc2)),
+                                                       _ptr(mlp.fc2.bias.detach()) if mlp.fc2.bias is not None else None,
+                                                       c, _ptr(xc), _ptr(out), st), "mirx_linear_split3_nchw")
+            return out
         y = self.mlp(self.norm(y))
         return y.permute(0, 3, 1, 2) + x
 

@@ -186,6 +186,26 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream);
 
 /*
+ * Tail of a ConvNeXtV2 block (timm ConvNeXtBlock.forward, used by the reference's model.py:87-118): the second
+ * point-wise Linear on the channels-last hidden map, written back channels-first with the block's skip added:
+ *     y[b, j, p] = residual[b, j, p] + sum_k x[b * tpi + p, k] W[j, k] + bias[j]
+ * x = device fp32 [n_img * tokens_per_image, k]; w3 as in mirx_linear_split3; residual / y = device fp32
+ * [n_img, n, tokens_per_image] (NCHW); residual NULL = no skip; y may alias residual.
+ */
+int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
+                            const float *bias_or_null, int n, const float *residual_or_null, float *y, void *stream);
+
+/*
+ * Global response normalisation of ConvNeXtV2 (timm GlobalResponseNorm, channels last) as two HBM passes:
+ *   mirx_grn_norm_nhwc:  gx[b, c] = || x[b, :, c] ||_2              x = device fp32 [n, hw, c], gx = [n, c]
+ *   mirx_grn_apply_nhwc: x[b, p, c] = x[b, p, c] * scale[b, c] + shift[c]  in place (c % 4 == 0)
+ * with scale = 1 + weight * gx / (mean_c gx + 1e-6) and shift = bias formed by the caller on [n, c].
+ * n <= 65535.  Fixed summation order (bit-reproducible).
+ */
+int mirx_grn_norm_nhwc(const float *x, int64_t n, int hw, int c, float *gx, void *stream);
+int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream);
+
+/*
  * 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1, no bias): conv2 of
  * torchvision's _DenseLayer (model.py:53), as Winograd F(2x2,3x3) on fp32 MFMA.  x: device NCHW fp32
  * [n, 128, side, side] (packed), side = 56, 28, 14 or 7.  u: device fp32 [16 stages][16][8][32] = the

@@ -83,3 +83,65 @@ def test_vit_block_split3_matches_rocblas_path():
         finally:
             mm.SPLIT3_LINEAR = True
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("n_img,tpi,k,n,use_res", [(3, 144, 512, 128, True), (2, 577, 2048, 512, True),
+                                                   (5, 36, 64, 256, False), (1, 9216, 512, 128, True)])
+def test_linear_split3_nchw_matches_float64(n_img, tpi, k, n, use_res):
+    """ConvNeXt block tail: channels-last input, NCHW output with the skip added."""
+    from mirx import _lib
+    from mirx.model import _split3_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n_img + tpi + k)
+    x = torch.randn(n_img * tpi, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    res = torch.randn(n_img, n, tpi, generator=g).to(dev) if use_res else None
+    want = (x.double() @ w.double().t() + b.double()).reshape(n_img, tpi, n).permute(0, 2, 1)
+    if use_res:
+        want = want + res.double()
+    y = torch.full((n_img, n, tpi), float("nan"), device=dev)
+    _lib.check(lib.mirx_linear_split3_nchw(_vp(x), n_img, tpi, k, _vp(_split3_weights(w)), _vp(b), n, _vp(res), _vp(y),
+                                           None), "mirx_linear_split3_nchw")
+    torch.cuda.synchronize()
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+
+
+@pytest.mark.parametrize("n,hw,c", [(3, 144, 512), (2, 577, 192), (1, 5, 4), (4, 2304, 1024)])
+def test_grn_kernels_match_torch(n, hw, c):
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n + hw + c)
+    x = torch.randn(n, hw, c, device=dev) * 2.0
+    gx = torch.empty(n, c, device=dev)
+    _lib.check(lib.mirx_grn_norm_nhwc(_vp(x), n, hw, c, _vp(gx), None), "mirx_grn_norm_nhwc")
+    want = torch.linalg.vector_norm(x.double(), ord=2, dim=1)
+    assert float(((gx.double() - want) / want).abs().max()) < 2e-6
+    scale = torch.randn(n, c, device=dev)
+    shift = torch.randn(c, device=dev)
+    y = x.clone()
+    _lib.check(lib.mirx_grn_apply_nhwc(_vp(y), n, hw, c, _vp(scale), _vp(shift), None), "mirx_grn_apply_nhwc")
+    assert torch.equal(y, torch.addcmul(shift, x, scale[:, None, :]).float()) or \
+        float((y - (x * scale[:, None, :] + shift)).abs().max()) < 1e-5
+
+
+def test_convnext_block_fused_matches_module_path():
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    blk = mm._CnxBlock(128).to(dev).eval()
+    with torch.no_grad():
+        blk.mlp.grn.weight.normal_()
+        blk.mlp.grn.bias.normal_()
+        x = torch.randn(3, 128, 24, 24, device=dev)
+        got = blk(x)
+        mm.SPLIT3_LINEAR = False
+        try:
+            want = blk(x)
+        finally:
+            mm.SPLIT3_LINEAR = True
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
