@@ -10,7 +10,8 @@
 // Same contract as mirx_conv1x1_bn_relu (y = act_out(W * act_in(x) + bias), NCHW), except that the
 // weights arrive pre-split: w3 = [cout / 128][cin / 16][3 terms][128 out][16 in] bf16 (mirx.model
 // prepares it once per layer).  Workgroup tile 128 output channels x 128 pixels, 4 waves (2 x 2), one
-// 16-channel K step per stage, double-buffered LDS (48 KiB, 3 workgroups per CU), register prefetch.
+// 16-channel K step per stage, double-buffered LDS (48 KiB, 3 workgroups per CU); weights by LDS DMA,
+// activations register-prefetched.
 // Activations are split while they are staged: a thread owns one pixel and 8 consecutive channels (8
 // coalesced loads, BN + ReLU with wave-uniform scalars, three 16-byte LDS stores).  LDS rows are 32 B
 // (16 bf16); chunk c of row r sits at c ^ ((r >> 3) & 1): conflict-free ds_read_b128 for the hardware's
@@ -26,6 +27,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 constexpr int CM = 128;            // output channels per workgroup
 constexpr int CP = 128;            // pixels per workgroup
@@ -61,22 +63,23 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
     }
     const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * hw;
     const int b_lds = 3 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + term * PLANE_B
-    // A: the stage block [3][128][16] bf16 is 768 chunks of 16 B; thread -> chunks t, t + 256, t + 512
-    const uint16_t *wsrc = w3 + ((int64_t)blockIdx.y * nk) * (3 * CM * KC) + threadIdx.x * 8;
-    int a_lds[3];
+    // A: the 12 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
+    // piece base + 16 l), three 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
+    // l / 2, slot l & 1), which holds source chunk (l & 1) ^ ((row >> 3) & 1) -- the same for every piece.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w3 + ((int64_t)blockIdx.y * nk) * (3 * CM * KC)), 0, nk * (3 * CM * KC * 2), 0x00020000);
+    const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    auto dma_w = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int ch = threadIdx.x + 256 * i;            // chunk id: term = ch >> 8, row = (ch >> 1) & 127, c = ch & 1
-        const int row = (ch >> 1) & 127;
-        a_lds[i] = (ch >> 8) * PLANE_A + row * 32 + (((ch & 1) ^ ((row >> 3) & 1)) << 4);
-    }
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE + piece * 1024), 16, w_voff,
+                                                     kt * (3 * CM * KC * 2) + piece * 1024, 0, 0);
+        }
+    };
 
-    u32x4 ra[3];
     float rb[8], rsc[8], rsh[8];
     auto load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            ra[i] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (3 * CM * KC) + 2048 * i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) rb[j] = xsrc[((int64_t)kt * KC + j) * hw];
         if (PROLOGUE) {
@@ -89,8 +92,6 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
     };
     auto store = [&](int buf) {
         char *sb = sm + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4 *>(sb + a_lds[i]) = ra[i];
         // three bf16 terms of each value, two values at a time: fptrunc <2 x float> -> <2 x bfloat> is one
         // v_cvt_pk_bf16_f32 (round to nearest even) on gfx950
         u32x4 ph, pm, pl;
@@ -135,12 +136,18 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_s3(const float *__restrict__
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if (threadIdx.x < CM) sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+    dma_w(0, 0);
     load(0);
     store(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        __syncthreads();                                   // stage kt visible; buffer cur ^ 1 free
-        load(kt + 1 < nk ? kt + 1 : kt);                   // branch-free: the last stage re-loads itself
+        // stage kt visible (this wave's weight DMA has landed: vmcnt(0) -- the compiler's own wait before
+        // s_barrier does not cover the asynchronous LDS writes); buffer cur ^ 1 free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nxt = kt + 1 < nk ? kt + 1 : kt;         // branch-free: the last stage re-loads itself
+        dma_w(nxt, cur ^ 1);
+        load(nxt);
         __builtin_amdgcn_sched_barrier(0);
         const char *sb = sm + cur * STAGE;
         bf16x8 a[2][3], b[2][3];
