@@ -411,3 +411,62 @@ def run_late_fusion_experiments(aligned, alpha_values=(0.2, 0.4, 0.5, 0.6, 0.8),
         results.append(ExperimentResult(f"weighted_sum_alpha_{alpha:.1f}", n,
                                         metrics_of(_rank_embeddings(fusion.embeddings, dev))))
     return results
+
+
+# ---- test.py:599-647 (text-similarity re-ranking of the top-k image results) --------------------
+def text_rerank_scores(embeds, concept_image_embeds, text_embeds, labels, rerank_k, text_weight):
+    """The re-scored matrix ``dists`` of test.py:599-623 on the device, in one vectorised pass.
+
+    embeds [N, D] (unit rows, retrieval backbone), concept_image_embeds [N, E] and text_embeds [C, E]
+    (unit rows, the text tower's image / class-prompt features), labels [N] int.  For every query i the
+    ``min(rerank_k, N)`` best images by image similarity (ties: lowest id) get
+    ``alpha * sim[i, j] + (1 - alpha) * (concept_image[j] . text[labels[i]])`` with alpha = text_weight;
+    j == i and every other entry keep the image similarity; the diagonal becomes -inf.  Scores are fp64
+    (the reference keeps fp32: rankings can differ inside fp32 near-ties).  Returns the [N, N] fp64 tensor on
+    the embeddings' device; rows are queries for retrieval_accuracy, COLUMNS are what the reference's
+    ``argsort(dists, dim=0)`` ranks for compute_map -- kept as is by text_rerank_evaluate."""
+    e = torch.as_tensor(embeds).double()
+    dev = e.device
+    n = e.shape[0]
+    lab = torch.as_tensor(labels).to(dev).long()
+    sim = e @ e.t()
+    k = min(int(rerank_k), n)
+    dists = sim.clone()
+    if k > 0:
+        top = torch.sort(sim, dim=1, descending=True, stable=True).indices[:, :k]          # [N, k]
+        rows = torch.arange(n, device=dev)[:, None].expand(n, k)
+        it = torch.as_tensor(concept_image_embeds).to(dev).double() @ torch.as_tensor(text_embeds).to(dev).double().t()
+        text_score = it[top, lab[:, None].expand(n, k)]                                     # [N, k]: it[j, labels[i]]
+        base = sim.gather(1, top)
+        fused = float(text_weight) * base + (1.0 - float(text_weight)) * text_score
+        dists.scatter_(1, top, torch.where(top != rows, fused, base))
+    dists.fill_diagonal_(float("-inf"))
+    return dists
+
+
+def text_rerank_evaluate(embeds, concept_image_embeds, text_embeds, labels, rerank_k=20, text_weight=0.7,
+                         kappas=(1, 5, 10)):
+    """test.py:599-647: R@K from the rows of the re-scored matrix, mAP / mP@K from the ranking of its columns
+    (``argsort(dists, dim=0, descending=True)``, ties -> lowest id), all on the device."""
+    dists = text_rerank_scores(embeds, concept_image_embeds, text_embeds, labels, rerank_k, text_weight)
+    lab = torch.as_tensor(labels).to(dists.device).long()
+    kmax = min(max(kappas), dists.shape[0])
+    top_ids = torch.sort(dists, dim=1, descending=True, stable=True).indices[:, :kmax]
+    accuracy = _m.retrieval_accuracy(None, lab, topk=tuple(kappas), topk_ids=top_ids)
+    ranks = torch.sort(dists, dim=0, descending=True, stable=True).indices.to(torch.int32).contiguous()
+    m_ap, aps, pr, prs = _m.compute_map(ranks, lab, list(kappas))
+    return {"accuracy": np.array([float(a) for a in accuracy], dtype=np.float32), "mAP": m_ap, "aps": aps, "pr": pr,
+            "prs": prs}
+
+
+# ---- retrieval_analysis/rerank.py:10-26 ----------------------------------------------------------
+class Reranker:
+    """Hook of retrieval_analysis.compare_models: ``rerank(query, results) -> iterable of results``."""
+
+    def rerank(self, query, results):
+        raise NotImplementedError
+
+
+class IdentityReranker(Reranker):
+    def rerank(self, query, results):
+        return list(results)

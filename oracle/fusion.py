@@ -152,3 +152,32 @@ def align_records(conv_records, dino_records, strict_label_check=True):
         raise ValueError("No aligned samples found across the requested sources")
     return {"image_paths": paths, "labels": labels, "conv_embeddings": np.stack(ce).astype(np.float32),
             "dino_embeddings": np.stack(de).astype(np.float32), "coverage": coverage}
+
+
+# -- test.py:599-623 (loops kept as the reference writes them; fp64 scores, ties -> lowest id) -------------
+def text_rerank_dists(embeds, concept_image_embeds, text_embeds, labels, rerank_k, text_weight):
+    e = np.asarray(embeds, dtype=np.float64)
+    img_sim = e @ e.T
+    img_text_sim = np.asarray(concept_image_embeds, dtype=np.float64) @ np.asarray(text_embeds, dtype=np.float64).T
+    dists = img_sim.copy()
+    alpha = float(text_weight)
+    beta = 1.0 - alpha
+    n = len(labels)
+    for i in range(n):
+        top = np.argsort(-img_sim[i], kind="stable")[: min(int(rerank_k), n)]
+        for j in top:
+            if i != j:
+                dists[i, j] = alpha * img_sim[i, j] + beta * img_text_sim[j, labels[i]]
+    np.fill_diagonal(dists, -np.inf)
+    return dists
+
+
+# -- test.py:625-638: R@K from rows (topk dim 1), mAP / mP@K from the ranking of COLUMNS (argsort dim 0) ------
+def text_rerank_metrics(dists, labels, kappas=(1, 5, 10)):
+    labels = np.asarray(labels)
+    order = np.argsort(-dists, axis=1, kind="stable")[:, : max(kappas)]
+    correct = labels[order] == labels[:, None]
+    acc = np.array([100.0 * np.count_nonzero(correct[:, :k].any(axis=1)) / len(labels) for k in kappas])
+    ranks = np.argsort(-dists, axis=0, kind="stable")
+    m_ap, aps, pr, prs = om.compute_map(ranks, labels, list(kappas))
+    return acc, m_ap, pr
