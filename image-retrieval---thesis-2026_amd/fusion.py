@@ -453,7 +453,7 @@ def text_rerank_evaluate(embeds, concept_image_embeds, text_embeds, labels, rera
     kmax = min(max(kappas), dists.shape[0])
     top_ids = torch.sort(dists, dim=1, descending=True, stable=True).indices[:, :kmax]
     accuracy = _m.retrieval_accuracy(None, lab, topk=tuple(kappas), topk_ids=top_ids)
-    ranks = torch.sort(dists, dim=0, descending=True, stable=True).indices.to(torch.int32).contiguous()
+    ranks = torch.sort(dists, dim=0, descending=True, stable=True).indices            # [N, N]: column q = query q
     m_ap, aps, pr, prs = _m.compute_map(ranks, lab, list(kappas))
     return {"accuracy": np.array([float(a) for a in accuracy], dtype=np.float32), "mAP": m_ap, "aps": aps, "pr": pr,
             "prs": prs}
