@@ -17,7 +17,8 @@
 //   O^T[d, q]  += V^T[d, key] . P^T[key, q]  A = V tile (LDS), B = P straight from the registers above:
 //       the contraction visits the keys in the order k(r), half -- V rows are fetched in that order.
 // K is staged de-interleaved by channel parity (the A operand of step s is channel 2s + half), rows
-// padded to 36 floats so the ds_read_b128 of 16 different keys hit 16 different bank groups.
+// pitched at 4 mod 8 floats (36 for head_dim 64 and 72) so the ds_read_b128 of 16 different keys hit 16
+// different bank groups.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -27,13 +28,20 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int DH = 64;                 // head dimension
 constexpr int KT = 32;                 // keys per tile
-constexpr int KP = 36;                 // pitch of a K parity plane row (32 used)
-constexpr int VP = 64;                 // pitch of a V row
 
+// DH = head dimension, a multiple of 8 up to 96 (64: DINOv2 / ViT-B; 72: the SigLIP-So400m tower of MedSigLIP).
+// A head wider than a multiple of 32 pays a partly idle third output tile (72: 84 MFMAs per key tile for 72
+// channels' worth instead of 64 for 64).
+template <int DH>
 __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv, int n, int heads, float scale_log2e,
                                                    float *__restrict__ out) {
+    constexpr int HP = DH / 2;                           // channels per parity plane
+    constexpr int KP = (HP % 8 == 4) ? HP : HP + 4;      // plane row pitch = 4 mod 8 floats: 16 keys' ds_read_b128 hit 16 bank groups
+    constexpr int VP = DH;                               // pitch of a V row
+    constexpr int NT = (DH + 31) / 32;                   // output tiles of 32 channels
+    constexpr int C4 = DH / 4;                           // float4 chunks of a key row
+    constexpr int CPT = (C4 + 7) / 8;                    // chunks per staging thread
     __shared__ __attribute__((aligned(16))) float s_k[2][2][KT][KP];      // [buffer][parity][key][channel / 2]
     __shared__ __attribute__((aligned(16))) float s_v[2][KT][VP];         // [buffer][key][channel]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -46,39 +54,45 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
     const int q_ld = q_idx < n ? q_idx : n - 1;
 
     // this lane's query, channels 2s + half, pre-multiplied by scale * log2(e): softmax runs on exp2
-    float qf[32];
+    float qf[HP];
     {
         const float *qp = base + q_ld * tok + half;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) qf[s] = qp[2 * s] * scale_log2e;
+        for (int s = 0; s < HP; ++s) qf[s] = qp[2 * s] * scale_log2e;
     }
 
-    // staging: thread -> key t / 8, float4 chunks 2 (t & 7), 2 (t & 7) + 1 of K and of V
-    const int st_key = threadIdx.x >> 3, st_c = (threadIdx.x & 7) * 2;
-    f32x4 rk[2], rv[2];
+    // staging: thread -> key t / 8, float4 chunks (t & 7), (t & 7) + 8, ... of K and of V (8 threads = 128 B)
+    const int st_key = threadIdx.x >> 3, st_c = threadIdx.x & 7;
+    f32x4 rk[CPT], rv[CPT];
     auto load_tile = [&](int kt) {
         int key = kt * KT + st_key;
         if (key >= n) key = n - 1;                                        // masked later
-        const float *kp = base + key * tok + heads * DH + st_c * 4;
-        rk[0] = *reinterpret_cast<const f32x4 *>(kp);
-        rk[1] = *reinterpret_cast<const f32x4 *>(kp + 4);
-        rv[0] = *reinterpret_cast<const f32x4 *>(kp + heads * DH);
-        rv[1] = *reinterpret_cast<const f32x4 *>(kp + heads * DH + 4);
+        const float *kp = base + key * tok + heads * DH;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = st_c + 8 * j;
+            if (c < C4) {
+                rk[j] = *reinterpret_cast<const f32x4 *>(kp + 4 * c);
+                rv[j] = *reinterpret_cast<const f32x4 *>(kp + heads * DH + 4 * c);
+            }
+        }
     };
     auto store_tile = [&](int buf) {
-        // channels 8 st_c' .. : float4 j covers channels 4 (st_c + j) .. + 3 -> parity planes, index channel / 2
+        // float4 chunk c covers channels 4 c .. 4 c + 3 -> parity planes, index channel / 2
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c2 = 2 * (st_c + j);                                 // (channel / 2) of the first element
-            *reinterpret_cast<float2 *>(&s_k[buf][0][st_key][c2]) = make_float2(rk[j][0], rk[j][2]);
-            *reinterpret_cast<float2 *>(&s_k[buf][1][st_key][c2]) = make_float2(rk[j][1], rk[j][3]);
-            *reinterpret_cast<f32x4 *>(&s_v[buf][st_key][4 * (st_c + j)]) = rv[j];
+        for (int j = 0; j < CPT; ++j) {
+            const int c = st_c + 8 * j;
+            if (c < C4) {
+                *reinterpret_cast<float2 *>(&s_k[buf][0][st_key][2 * c]) = make_float2(rk[j][0], rk[j][2]);
+                *reinterpret_cast<float2 *>(&s_k[buf][1][st_key][2 * c]) = make_float2(rk[j][1], rk[j][3]);
+                *reinterpret_cast<f32x4 *>(&s_v[buf][st_key][4 * c]) = rv[j];
+            }
         }
     };
 
-    f32x16 o[2];
+    f32x16 o[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
@@ -92,9 +106,9 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
         if (kt + 1 < ntiles) load_tile(kt + 1);
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
-        float kf[32];
+        float kf[HP];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < HP / 4; ++c) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_k[cur][half][nq][4 * c]);
             kf[4 * c] = v[0]; kf[4 * c + 1] = v[1]; kf[4 * c + 2] = v[2]; kf[4 * c + 3] = v[3];
         }
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sacc, 0, 0, 0);
+        for (int s = 0; s < HP; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sacc, 0, 0, 0);
 
         // ---- online softmax over this lane's 16 keys (base 2) --------------------------------------
         const int key0 = kt * KT + 4 * half;
@@ -125,16 +139,20 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
 
         // ---- O^T += V^T P^T: step r contracts keys k(r) (half 0) and k(r) + 4 (half 1) ------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float *vrow = &s_v[cur][8 * (r >> 2) + (r & 3) + 4 * half][nq];
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], sacc[r], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], sacc[r], o[1], 0, 0, 0);
+            const float *vrow = &s_v[cur][8 * (r >> 2) + (r & 3) + 4 * half][0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                // a partly filled last tile: the lanes beyond DH re-read channel DH - 1; their output rows are dropped
+                const int ch = (32 * t + 31 < DH) ? 32 * t + nq : (32 * t + nq < DH ? 32 * t + nq : DH - 1);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[ch], sacc[r], o[t], 0, 0, 0);
+            }
         }
         if (kt + 1 < ntiles) store_tile(cur ^ 1);
     }
@@ -145,9 +163,10 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
         const float inv = 1.0f / l_run;
         float *op = out + ((img * n + q_idx) * heads + head) * DH + 4 * half;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (32 * t + 8 * g + 4 * half >= DH) continue;
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
@@ -161,9 +180,16 @@ __global__ __launch_bounds__(256) void k_attention(const float *__restrict__ qkv
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                             hipStream_t st) {
     if (batch <= 0 || n <= 0) return hipSuccess;
-    if (head_dim != DH || heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
-    hipLaunchKernelGGL(k_attention, grid, dim3(256), 0, st, qkv, n, heads, scale * 1.4426950408889634f, out);
+    const float sl = scale * 1.4426950408889634f;
+    switch (head_dim) {
+        case 32: hipLaunchKernelGGL(k_attention<32>, grid, dim3(256), 0, st, qkv, n, heads, sl, out); break;
+        case 64: hipLaunchKernelGGL(k_attention<64>, grid, dim3(256), 0, st, qkv, n, heads, sl, out); break;
+        case 72: hipLaunchKernelGGL(k_attention<72>, grid, dim3(256), 0, st, qkv, n, heads, sl, out); break;
+        case 96: hipLaunchKernelGGL(k_attention<96>, grid, dim3(256), 0, st, qkv, n, heads, sl, out); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

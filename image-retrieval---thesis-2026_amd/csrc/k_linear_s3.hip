@@ -4,7 +4,7 @@
 // cross terms <= 3 * 2^-24 |w x|, i.e. the rounding class of one fp32 product).
 //
 //   x   [m][k] fp32, k contiguous (tokens x features)        -> MFMA row operand, split while it is staged
-//   w3  [n / 128][k / 16][3 terms][128][16] bf16              -> MFMA column operand (mirx.model._split3_weights)
+//   w3  [ceil(n / 128)][k / 16][3 terms][128][16] bf16, rows >= n zero -> MFMA column operand (mirx.model._split3_weights)
 //   y   [m][n] fp32:  v = acc + bias[n];  ACT == 1: v = gelu(v) (erf form);
 //                     RES: v = res[m][n] + gamma[n] * v  (LayerScale + residual; y may alias res)
 //   NCHW variant (ConvNeXt block tail): token t = image t / tpi, pixel t % tpi; y and res are [image][n][tpi].
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int col = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (col >= n) continue;                     // zero-padded weight rows of the last output tile
                     float v = acc[mi][ni][r] + (bias ? bias[col] : 0.f);
                     if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     const int64_t idx = base + (int64_t)col * tpi;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = n0 + wn * 64 + 32 * ni + (lane & 31);
+        if (col >= n) continue;                                 // zero-padded weight rows of the last output tile
         const float bv = bias ? bias[col] : 0.f;
         const float gv = (RES && gamma) ? gamma[col] : 1.f;
 #pragma unroll
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,
                             const float *res, const float *gamma, float *y, int tokens_per_image, hipStream_t st) {
     if (m <= 0) return hipSuccess;
-    if (k % KC || n % TN || act < 0 || act > 1 || tokens_per_image < 0) return hipErrorInvalidValue;
-    const int ntn = n / TN;
+    if (k % KC || n < 1 || act < 0 || act > 1 || tokens_per_image < 0) return hipErrorInvalidValue;
+    const int ntn = (n + TN - 1) / TN;                 // w3 holds ntn * 128 rows, zero beyond n
     const int64_t total = ((m + TM - 1) / TM) * ntn;
     const int64_t per_xcd = (total + 7) / 8;
     if (per_xcd * 8 > 0x7fffffff) return hipErrorInvalidValue;

@@ -648,8 +648,7 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
 
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream) {
-    MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 128 && n % 128 == 0,
-               "linear_split3: k must be a multiple of 16 and n of 128");
+    MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split3: k must be a multiple of 16");
     MIRX_CHECK(act == 0 || act == 1, "linear_split3: act is 0 (none) or 1 (gelu)");
     MIRX_CHECK(m == 0 || (x && w3 && y), "linear_split3: null buffer");
     MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split3: gamma scales the residual branch only");
@@ -661,8 +660,8 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
 
 int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
                             const float *bias_or_null, int n, const float *residual_or_null, float *y, void *stream) {
-    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 128 && n % 128 == 0,
-               "linear_split3_nchw: k must be a multiple of 16 and n of 128");
+    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 1,
+               "linear_split3_nchw: k must be a multiple of 16");
     MIRX_CHECK(n_img == 0 || (x && w3 && y), "linear_split3_nchw: null buffer");
     MIRX_CHECK(x != y, "linear_split3_nchw: y may alias the residual, not the input");
     MIRX_HIP(launch_linear_s3(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, 0,
@@ -696,7 +695,8 @@ int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int si
 int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
                            float *out, void *stream) {
     MIRX_CHECK(batch >= 0 && n_tokens >= 0 && heads >= 1, "attention: bad sizes");
-    MIRX_CHECK(head_dim == 64, "attention: head_dim must be 64");
+    MIRX_CHECK(head_dim == 32 || head_dim == 64 || head_dim == 72 || head_dim == 96,
+               "attention: head_dim must be 32, 64, 72 or 96");
     MIRX_CHECK(batch == 0 || n_tokens == 0 || (qkv && out), "attention: null buffer");
     MIRX_CHECK(batch <= 65535 && heads <= 65535, "attention: batch and heads must be <= 65535");
     MIRX_HIP(launch_attention(qkv, batch, n_tokens, heads, head_dim, scale, out, reinterpret_cast<hipStream_t>(stream)));

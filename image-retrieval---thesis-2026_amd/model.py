@@ -241,6 +241,8 @@ def _split3_weights(w):
     """[cout, cin] fp32 -> the three bf16 terms of every weight (w = h + m + l exactly, 3 x 8 mantissa
     bits), laid out for mirx_conv1x1_bn_relu_split3: [cout // 128][cin // 16][3][128][16] bf16."""
     w = w.detach().float()
+    if w.shape[0] % 128:                               # Linear layers: zero rows up to the next output tile
+        w = F.pad(w, (0, 0, 0, 128 - w.shape[0] % 128))
     h = w.to(torch.bfloat16)
     m = (w - h.float()).to(torch.bfloat16)
     lo = (w - h.float() - m.float()).to(torch.bfloat16)
@@ -269,7 +271,7 @@ SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA
 
 def _linear_s3_ok(mod, x):
     return (SPLIT3_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-            and mod.in_features % 16 == 0 and mod.out_features % 128 == 0)
+            and mod.in_features % 16 == 0)
 
 
 def _linear_w3(mod):
@@ -281,6 +283,70 @@ def _linear_w3(mod):
         cached = (key, _split3_weights(w.detach()))
         mod._mirx_w3 = cached
     return cached[1]
+
+
+def _accelerate_linears(root):
+    """Route every nn.Linear under `root` (third-party module trees: the transformers SigLIP tower) through
+    mirx_linear_split3 for CUDA fp32 inference; anything else (training, CPU, odd widths) takes the module's
+    own forward."""
+    for mod in root.modules():
+        if type(mod) is nn.Linear and not getattr(mod, "_mirx_routed", False):
+            def fwd(x, _m=mod, _orig=mod.forward):
+                return _linear_s3(_m, x) if _linear_s3_ok(_m, x) else _orig(x)
+            mod.forward = fwd
+            mod._mirx_routed = True
+
+
+class _PackedQKV:
+    """q_proj / k_proj / v_proj of a third-party attention module seen as ONE Linear [3C, C]: its output is the
+    packed [B, N, 3, heads, head_dim] tensor mirx_attention_qkv_f32 reads (duck-typed for _linear_s3)."""
+
+    def __init__(self, att):
+        self.att = att
+        self.in_features = att.q_proj.in_features
+        self.out_features = 3 * att.q_proj.out_features
+        self._key = None
+
+    def _refresh(self):
+        ws = (self.att.q_proj.weight, self.att.k_proj.weight, self.att.v_proj.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if key != self._key:
+            self.weight = torch.cat([w.detach() for w in ws], 0)
+            bs = (self.att.q_proj.bias, self.att.k_proj.bias, self.att.v_proj.bias)
+            self.bias = None if bs[0] is None else torch.cat([b.detach() for b in bs], 0)
+            self._key = key
+
+
+_FUSED_TOWER_ATTENTION = [False]        # set by MedSigLIP.forward only: other callers may ask for attention maps
+
+
+def _route_tower_attention(root):
+    """transformers SiglipAttention (q/k/v/out projections around softmax(q k^T / sqrt(d)) v): for CUDA fp32
+    inference without mask, run packed-qkv Linear -> mirx_attention_qkv_f32 -> out Linear.  Only while
+    _FUSED_TOWER_ATTENTION is set (the embedding forward): the module's own forward still serves callers that
+    read attention weights (the reference's rollout explainer, model.py:546-551)."""
+    for mod in root.modules():
+        if (mod.__class__.__name__ == "SiglipAttention" and not getattr(mod, "_mirx_routed", False)
+                and all(hasattr(mod, a) for a in ("q_proj", "k_proj", "v_proj", "out_proj", "head_dim", "scale"))):
+            packed = _PackedQKV(mod)
+
+            def fwd(hidden_states, attention_mask=None, _m=mod, _orig=mod.forward, _p=packed, **kw):
+                x = hidden_states
+                if (_FUSED_TOWER_ATTENTION[0] and attention_mask is None and x.dim() == 3
+                        and _m.head_dim in (32, 64, 72, 96) and _linear_s3_ok(_p, x) and x.shape[0] <= 65535):
+                    _p._refresh()
+                    b, n, c = x.shape
+                    qkv = _linear_s3(_p, x)
+                    a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
+                    with torch.cuda.device(x.device):
+                        _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, c // _m.head_dim, _m.head_dim,
+                                                                      float(_m.scale), _ptr(a), _stream(x.device)),
+                                   "mirx_attention_qkv_f32")
+                    return _m.out_proj(a), None
+                return _orig(hidden_states, attention_mask, **kw)
+
+            mod.forward = fwd
+            mod._mirx_routed = True
 
 
 def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
@@ -843,6 +909,8 @@ class MedSigLIP(nn.Module):
                 p.requires_grad = True
         hidden = self.backbone.config.hidden_size
         self.projection = nn.Sequential(nn.Linear(hidden, 512), nn.LayerNorm(512), nn.ReLU(), nn.Linear(512, embed_dim))
+        _accelerate_linears(self)                      # q/k/v/out projections, MLPs (4304 wide: padded tile), head
+        _route_tower_attention(self.backbone)          # head_dim 72 flash attention on the packed projection
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             for key in ("state-dict", "state_dict"):
@@ -863,7 +931,11 @@ class MedSigLIP(nn.Module):
         return out.attentions is not None and len(out.attentions) > 0 and out.attentions[0].numel() > 0
 
     def forward(self, x):
-        features = self.backbone(pixel_values=x).pooler_output
+        _FUSED_TOWER_ATTENTION[0] = True               # embedding extraction never reads attention maps
+        try:
+            features = self.backbone(pixel_values=x).pooler_output
+        finally:
+            _FUSED_TOWER_ATTENTION[0] = False
         return _normalize_rows(self.projection(features))
 
 

@@ -178,9 +178,9 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
  *     y[i, j] = epi( sum_k x[i, k] W[j, k] + bias[j] )
  *     act = 1: exact (erf) GELU;  residual != NULL:  y = residual + gamma[j] * v  (LayerScale + skip; gamma
  *     NULL = 1; y may alias residual).
- * x = device fp32 [m, k] row-major; w3 = device bf16 [n / 128][k / 16][3][128][16] (the layout of
- * mirx_conv1x1_bn_relu_split3, mirx.model._split3_weights(W)); y = device fp32 [m, n].
- * k % 16 == 0, n % 128 == 0, any m >= 0.
+ * x = device fp32 [m, k] row-major; w3 = device bf16 [ceil(n / 128)][k / 16][3][128][16] (the layout of
+ * mirx_conv1x1_bn_relu_split3, mirx.model._split3_weights(W); weight rows beyond n are zero padding);
+ * y = device fp32 [m, n].  k % 16 == 0, any n >= 1, any m >= 0.
  */
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream);
@@ -222,7 +222,8 @@ int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int si
  * head), scores never materialised.  Replaces the attention of timm's `vit_base_patch14_dinov2`
  * blocks (model.py:459-463; nih_multilabel_retrieval.py:175-221).  qkv: device [batch, n_tokens, 3,
  * heads, head_dim] fp32, exactly the output of the block's qkv Linear; out: device [batch, n_tokens,
- * heads, head_dim] fp32 (= [batch, n_tokens, C], no head transpose).  head_dim must be 64.
+ * heads, head_dim] fp32 (= [batch, n_tokens, C], no head transpose).  head_dim in {32, 64, 72, 96}
+ * (64: ViT-B / DINOv2; 72: the SigLIP-So400m tower of MedSigLIP, model.py:536-638).
  */
 int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
                            float scale, float *out, void *stream);

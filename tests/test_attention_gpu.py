@@ -29,11 +29,22 @@ def _ref(qkv):
 
 @pytest.mark.parametrize("b,n,heads", [(1, 1, 1), (2, 5, 3), (1, 32, 2), (1, 33, 1), (3, 127, 2), (2, 128, 12),
                                        (1, 129, 1), (2, 257, 12), (1, 1370, 12)])
-def test_attention_matches_float64(b, n, heads):
+@pytest.mark.parametrize("dh", [64, 72])
+def test_attention_matches_float64(b, n, heads, dh):
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1000 * n + heads)
-    qkv = torch.randn((b, n, 3, heads, 64), generator=g, device=dev) * 1.5
+    qkv = torch.randn((b, n, 3, heads, dh), generator=g, device=dev) * 1.5
     out = _run(qkv, heads)
+    ref = _ref(qkv)
+    assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dh", [32, 96])
+def test_attention_other_head_dims(dh):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(dh)
+    qkv = torch.randn((2, 77, 3, 3, dh), generator=g, device=dev)
+    out = _run(qkv, 3)
     ref = _ref(qkv)
     assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
 
@@ -54,8 +65,8 @@ def test_attention_peaked_and_large_logits():
 def test_attention_argument_errors():
     from mirx import _lib
     lib = _lib.load()
-    x = torch.zeros((1, 4, 3, 1, 32), device="cuda:0")
-    rc = lib.mirx_attention_qkv_f32(ctypes.c_void_p(x.data_ptr()), 1, 4, 1, 32, 0.1, ctypes.c_void_p(x.data_ptr()), None)
+    x = torch.zeros((1, 4, 3, 1, 40), device="cuda:0")
+    rc = lib.mirx_attention_qkv_f32(ctypes.c_void_p(x.data_ptr()), 1, 4, 1, 40, 0.1, ctypes.c_void_p(x.data_ptr()), None)
     assert rc == -1 and b"head_dim" in lib.mirx_last_error()          # MIRX_EINVAL
     assert lib.mirx_attention_qkv_f32(None, 0, 0, 1, 64, 0.1, None, None) == 0
 

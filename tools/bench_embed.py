@@ -20,14 +20,21 @@ def main():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-hip-stem", action="store_true")
     ap.add_argument("--no-hip-conv1x1", action="store_true")
-    ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2", "dinov2"])
+    ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2", "dinov2", "medsiglip"])
+    ap.add_argument("--no-split3-linear", action="store_true")
     a = ap.parse_args()
+    if a.no_split3_linear:
+        import mirx.model as mm
+        mm.SPLIT3_LINEAR = False
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     if a.model == "convnextv2":
         m = ConvNeXtV2(embedding_dim=256).eval().to(dev)
     elif a.model == "dinov2":
         m = DinoV2(embedding_dim=256).eval().to(dev)
+    elif a.model == "medsiglip":
+        from mirx.model import MedSigLIP
+        m = MedSigLIP().eval().to(dev)
     else:
         m = DenseNet121().eval().to(dev)
         m.use_hip_stem = not a.no_hip_stem
