@@ -71,6 +71,9 @@ hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3
 // ---- k_conv3x3.hip ----------------------------------------------------------------------
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
                                hipStream_t st);
+// ---- k_conv3x3_s3.hip: the same convolution on three-term bf16 MFMAs (side 56 / 28 / 14) ----------
+hipError_t launch_conv3x3_wino_s3(const float *x, const uint16_t *u3, int64_t n, int side, float *out, int64_t out_bs,
+                                  hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

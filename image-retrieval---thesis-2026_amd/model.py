@@ -137,11 +137,17 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
                            "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
             if use_hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
-                # Winograd F(2x2,3x3) on fp32 MFMA, written straight into this layer's slice of the buffer
-                _lib.check(lib.mirx_conv3x3_winograd_nchw(_ptr(y), _ptr(u3), b, h,
-                                                          ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w),
-                                                          block.cout * h * w, _stream(x.device)),
-                           "mirx_conv3x3_winograd_nchw")
+                # Winograd F(2x2,3x3), written straight into this layer's slice of the buffer: three-term bf16
+                # MFMAs on the 28 / 14 maps (8-11 % faster there), fp32 MFMAs on the 56 (3 % slower with the split:
+                # operand delivery, not the matrix pipe, bounds it) and 7 x 7 maps
+                dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
+                if h in SPLIT3_CONV3X3:
+                    _lib.check(lib.mirx_conv3x3_winograd_split3_nchw(_ptr(y), _ptr(u3[1]), b, h, dst, block.cout * h * w,
+                                                                     _stream(x.device)),
+                               "mirx_conv3x3_winograd_split3_nchw")
+                else:
+                    _lib.check(lib.mirx_conv3x3_winograd_nchw(_ptr(y), _ptr(u3[0]), b, h, dst, block.cout * h * w,
+                                                              _stream(x.device)), "mirx_conv3x3_winograd_nchw")
             else:
                 buf[:, c: c + GROWTH] = F.conv2d(y, layer.conv2.weight, None, padding=1)
             c += GROWTH
@@ -237,6 +243,20 @@ def _winograd_weights(w):
     return u.contiguous()
 
 
+def _winograd_weights_split3(w):
+    """conv2 weights [32, 128, 3, 3] -> the three bf16 terms of U = G g G^T, laid out for
+    mirx_conv3x3_winograd_split3_nchw: [stage = c // 16][xi = 4 i + j][term][oc][c % 16] bf16."""
+    g = w.detach().float()
+    gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], device=g.device)
+    u = torch.einsum("ik,ockl,jl->ocij", gm, g, gm)                       # [oc, c, 4, 4]
+    h = u.to(torch.bfloat16)
+    m = (u - h.float()).to(torch.bfloat16)
+    lo = (u - h.float() - m.float()).to(torch.bfloat16)
+    oc, cin = u.shape[0], u.shape[1]
+    t = torch.stack([h, m, lo], 0).reshape(3, oc, cin // 16, 16, 16)      # [term, oc, stage, c % 16, xi]
+    return t.permute(2, 4, 0, 1, 3).contiguous()
+
+
 def _split3_weights(w):
     """[cout, cin] fp32 -> the three bf16 terms of every weight (w = h + m + l exactly, 3 x 8 mantissa
     bits), laid out for mirx_conv1x1_bn_relu_split3: [cout // 128][cin // 16][3][128][16] bf16."""
@@ -266,6 +286,7 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+SPLIT3_CONV3X3 = (28, 14)   # map sides whose dense-layer 3x3 convs run the Winograd GEMMs on three-term bf16 MFMAs
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
 
 
@@ -429,7 +450,8 @@ class DenseNet121(nn.Module):
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
                     w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
-                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t, _winograd_weights(layer.conv2.weight),
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t,
+                                  (_winograd_weights(layer.conv2.weight), _winograd_weights_split3(layer.conv2.weight)),
                                   _split3_weights(w1.view(w1.shape[0], w1.shape[1])))
                 cache[name] = blk
             elif name.startswith("transition"):

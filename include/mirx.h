@@ -218,6 +218,15 @@ int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int si
                                int64_t out_batch_stride, void *stream);
 
 /*
+ * mirx_conv3x3_winograd_nchw with the 16 Winograd-domain channel GEMMs on three-term bf16 MFMAs (fp32-grade,
+ * see mirx_conv1x1_bn_relu_split3): same x / out / out_batch_stride; u3 = device bf16
+ * [cin / 16][ij = 4 i + j][3 terms][32 oc][16 channels], the split of U = G g G^T
+ * (mirx.model._winograd_weights_split3).  side in {56, 28, 14}; the 7 x 7 maps use mirx_conv3x3_winograd_nchw.
+ */
+int mirx_conv3x3_winograd_split3_nchw(const float *x, const void *u3, int64_t n, int side, float *out,
+                                      int64_t out_batch_stride, void *stream);
+
+/*
  * Multi-head self-attention of the ViT backbones, fp32: out = softmax(q k^T * scale) v per (image,
  * head), scores never materialised.  Replaces the attention of timm's `vit_base_patch14_dinov2`
  * blocks (model.py:459-463; nih_multilabel_retrieval.py:175-221).  qkv: device [batch, n_tokens, 3,

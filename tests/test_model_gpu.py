@@ -178,6 +178,41 @@ def test_winograd_conv3x3_matches_direct_conv(side, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side,batch", [(56, 3), (28, 5), (14, 9), (14, 1)])
+def test_winograd_split3_conv3x3_matches_direct_conv(side, batch):
+    """mirx_conv3x3_winograd_split3_nchw (Winograd-domain GEMMs on three-term bf16 MFMAs) against a float64
+    direct convolution and against the fp32-MFMA kernel: same tolerance as the fp32 kernel (2e-5 of the largest
+    output, the Winograd transform's own error), and within 3e-6 of that kernel (the split's own error)."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _winograd_weights, _winograd_weights_split3
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side + 100)
+    x = torch.randn(batch, 128, side, side, generator=g, device=dev)
+    x = torch.relu(x) * 1.7                                        # post-ReLU statistics, like conv2's real input
+    w = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    buf = torch.full((batch, 96, side, side), 7.0, device=dev)
+    ref = torch.full((batch, 96, side, side), 7.0, device=dev)
+    c0 = 40
+    u3 = _winograd_weights_split3(w)
+    assert u3.shape == (8, 16, 3, 32, 16) and u3.dtype == torch.bfloat16
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    _lib.check(lib.mirx_conv3x3_winograd_split3_nchw(vp(x), vp(u3), batch, side, vp(buf, 4 * c0 * side * side),
+                                                     96 * side * side, None), "conv3x3_split3")
+    _lib.check(lib.mirx_conv3x3_winograd_nchw(vp(x), vp(_winograd_weights(w)), batch, side, vp(ref, 4 * c0 * side * side),
+                                              96 * side * side, None), "conv3x3")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    got = buf[:, c0:c0 + 32].double().cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-5 * scale
+    assert float((buf[:, c0:c0 + 32] - ref[:, c0:c0 + 32]).abs().max()) < 3e-6 * scale
+    assert bool((buf[:, :c0] == 7.0).all()) and bool((buf[:, c0 + 32:] == 7.0).all())      # neighbours untouched
+    assert lib.mirx_conv3x3_winograd_split3_nchw(vp(x), vp(u3), batch, 7, vp(buf), 96 * side * side, None) == -1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(256, 256), (160, 192), (112, 112)])
 def test_embeddings_at_other_resolutions(model_and_sd, size):
     """Inputs whose feature maps are not 56/28/14/7 (the reference resizes to 224, read_data.py, but the
