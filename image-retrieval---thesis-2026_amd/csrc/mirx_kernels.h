@@ -78,6 +78,9 @@ hipError_t launch_conv3x3_wino_s3(const float *x, const uint16_t *u3, int64_t n,
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                             hipStream_t st);
+// ---- k_attention_s3.hip: the same attention on three-term bf16 MFMAs (head_dim 64) ------------------
+hipError_t launch_attention_s3(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
+                               hipStream_t st);
 
 // ---- k_metrics.hip ----------------------------------------------------------------------
 constexpr int MIRX_MAX_KAPPAS = 8;

@@ -287,6 +287,7 @@ def _stream(dev):
 
 
 SPLIT3_CONV3X3 = (28, 14)   # map sides whose dense-layer 3x3 convs run the Winograd GEMMs on three-term bf16 MFMAs
+SPLIT3_ATTENTION = True  # head_dim-64 attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
 
 
@@ -718,8 +719,10 @@ class _VitAttention(nn.Module):
             qkv = qkv.contiguous()
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
-                _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, self.num_heads, dh, float(dh) ** -0.5,
-                                                              _ptr(a), _stream(x.device)), "mirx_attention_qkv_f32")
+                lib = _lib.load()
+                att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                _lib.check(att(_ptr(qkv), b, n, self.num_heads, dh, float(dh) ** -0.5, _ptr(a), _stream(x.device)),
+                           "mirx_attention_qkv_f32")
             return self.proj(a)
         qkv = qkv.reshape(b, n, 3, self.num_heads, dh).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])      # softmax(q k^T / sqrt(d)) v
@@ -758,8 +761,10 @@ class _VitBlock(nn.Module):
             qkv = _linear_s3(at.qkv, self.norm1(x))
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
-                _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a),
-                                                              _stream(x.device)), "mirx_attention_qkv_f32")
+                lib = _lib.load()
+                att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
+                           "mirx_attention_qkv_f32")
             x = _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma)
             hid = _linear_s3(self.mlp.fc1, self.norm2(x), act=1)
             return _linear_s3(self.mlp.fc2, hid, res=x, gamma=self.ls2.gamma, out=x)

@@ -238,6 +238,14 @@ int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int he
                            float scale, float *out, void *stream);
 
 /*
+ * mirx_attention_qkv_f32 with both GEMMs on three-term bf16 MFMAs (Q, K, V and the probabilities each carried
+ * as xh + xm + xl; fp32-grade, see mirx_conv1x1_bn_relu_split3): same arguments and result layout.
+ * head_dim must be 64.
+ */
+int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
+                                  float scale, float *out, void *stream);
+
+/*
  * Metric tail over ranked lists, on the device: one pass per query over its
  * ranking `ranks[q, 0..n)` (gallery row ids, best first; rows `row_stride` apart) gives
  *   out_ap[q]      AP of the list: ap_kind 0 = the trapezoidal compute_ap of test.py:58-92 summed the

@@ -10,14 +10,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(qkv, heads):
+def _run(qkv, heads, split3=False):
     from mirx import _lib
     lib = _lib.load()
     b, n, three, h, dh = qkv.shape
-    out = torch.empty((b, n, h * dh), dtype=torch.float32, device=qkv.device)
+    out = torch.full((b, n, h * dh), float("nan"), dtype=torch.float32, device=qkv.device)
     st = ctypes.c_void_p(torch.cuda.current_stream(qkv.device).cuda_stream)
-    _lib.check(lib.mirx_attention_qkv_f32(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, dh, float(dh) ** -0.5,
-                                          ctypes.c_void_p(out.data_ptr()), st), "mirx_attention_qkv_f32")
+    fn = lib.mirx_attention_qkv_f32_split3 if split3 else lib.mirx_attention_qkv_f32
+    _lib.check(fn(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, dh, float(dh) ** -0.5,
+                  ctypes.c_void_p(out.data_ptr()), st), "mirx_attention_qkv_f32")
     return out
 
 
@@ -37,6 +38,27 @@ def test_attention_matches_float64(b, n, heads, dh):
     out = _run(qkv, heads)
     ref = _ref(qkv)
     assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("b,n,heads", [(1, 1, 1), (2, 5, 3), (1, 32, 2), (1, 33, 1), (3, 127, 2), (2, 128, 12),
+                                       (1, 129, 1), (2, 257, 12), (1, 1370, 12)])
+def test_attention_split3_matches_float64(b, n, heads):
+    """mirx_attention_qkv_f32_split3: both GEMMs on three-term bf16 MFMAs; same tolerance as the fp32 kernel, and
+    a peaked case (logits ~ +-60)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1000 * n + heads + 7)
+    qkv = torch.randn((b, n, 3, heads, 64), generator=g, device=dev) * 1.5
+    out = _run(qkv, heads, split3=True)
+    ref = _ref(qkv)
+    assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+    qkv[:, :, 0] *= 4.0
+    qkv[:, n // 2, 1] *= 6.0
+    out = _run(qkv, heads, split3=True)
+    ref = _ref(qkv)
+    assert torch.isfinite(out).all()
+    # logits of +-50: the absolute error of a logit scales with sum |q_c k_c| (here ~2000): 3 * 2^-24 of that per
+    # dropped cross term, i.e. a few 1e-6 relative on the probabilities
+    assert float((out.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("dh", [32, 96])
