@@ -70,6 +70,7 @@ SYMBOLS = {
     "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_conv1x1_bn_relu": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_dwconv7x7_nchw_to_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "mirx_stem_conv7_bn_relu_pool_split3": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
 }
 

@@ -791,6 +791,15 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
     return MIRX_OK;
 }
 
+int mirx_stem_conv7_bn_relu_pool_split3(const float *x, const void *w3, const float *scale, const float *shift,
+                                        int64_t n, int h, int wd, float *y, void *stream) {
+    MIRX_CHECK(x && w3 && scale && shift && y && n >= 0 && n <= 65535, "stem_split3: null argument or batch > 65535");
+    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split3: H and W must be multiples of 4");
+    MIRX_HIP(launch_stem_s3(x, reinterpret_cast<const uint16_t *>(w3), scale, shift, n, h, wd, y,
+                            reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const float *scale, const float *shift,
                          const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,
                          void *stream) {

@@ -25,6 +25,9 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
                                    hipStream_t st);
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
+// k_stem_s3.hip: the same stem on three-term bf16 MFMAs; w3 = pre-split weights [2][11][3][32][16] bf16
+hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale, const float *shift, int64_t n, int h,
+                          int wd, float *y, hipStream_t st);
 
 // ---- k_conv1x1.hip ----------------------------------------------------------------------
 hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,

@@ -257,6 +257,23 @@ def _winograd_weights_split3(w):
     return t.permute(2, 4, 0, 1, 3).contiguous()
 
 
+def _stem_weights_split3(w):
+    """conv0 weights [64, 3, 7, 7] -> the three bf16 terms laid out for mirx_stem_conv7_bn_relu_pool_split3:
+    [2 oc blocks][11 steps][term][32 oc][16 k]; k = 8 g + i of step s is row (c, ky) = divmod(2 s + g, 7) and
+    kx = 0, 2, 4, 6, 1, 3, 5, (7 = zero) for i = 0..7; row 21 is zero."""
+    w = w.detach().float()
+    wk = torch.zeros((64, 22, 8), dtype=torch.float32, device=w.device)
+    rows = w.reshape(64, 21, 7)                                            # [oc, (c, ky), kx]
+    wk[:, :21, 0:4] = rows[:, :, 0::2]
+    wk[:, :21, 4:7] = rows[:, :, 1::2]
+    wk = wk.reshape(64, 11, 16)
+    h = wk.to(torch.bfloat16)
+    m = (wk - h.float()).to(torch.bfloat16)
+    lo = (wk - h.float() - m.float()).to(torch.bfloat16)
+    t = torch.stack([h, m, lo], 0).reshape(3, 2, 32, 11, 16)               # [term, block, oc, step, k]
+    return t.permute(1, 3, 0, 2, 4).contiguous()
+
+
 def _split3_weights(w):
     """[cout, cin] fp32 -> the three bf16 terms of every weight (w = h + m + l exactly, 3 x 8 mantissa
     bits), laid out for mirx_conv1x1_bn_relu_split3: [cout // 128][cin // 16][3][128][16] bf16."""
@@ -287,6 +304,7 @@ def _stream(dev):
 
 
 SPLIT3_CONV3X3 = (28, 14)   # map sides whose dense-layer 3x3 convs run the Winograd GEMMs on three-term bf16 MFMAs
+SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # head_dim-64 attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
 
@@ -474,9 +492,15 @@ class DenseNet121(nn.Module):
         if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
             sc, sh = cache["norm0"]
             y = torch.empty((b, INIT_FEATURES, h // 4, w // 4), dtype=torch.float32, device=x.device)
-            wt = f.conv0.weight.detach().float().contiguous()
-            _lib.check(lib.mirx_stem_conv7_bn_relu_pool(_ptr(x), _ptr(wt), _ptr(sc), _ptr(sh), b, h, w,
-                                                        _ptr(y), _stream(x.device)), "mirx_stem")
+            if SPLIT3_STEM and b <= 65535:
+                if "conv0_w3" not in cache:
+                    cache["conv0_w3"] = _stem_weights_split3(f.conv0.weight)
+                _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3(_ptr(x), _ptr(cache["conv0_w3"]), _ptr(sc), _ptr(sh),
+                                                                   b, h, w, _ptr(y), _stream(x.device)), "mirx_stem_split3")
+            else:
+                wt = f.conv0.weight.detach().float().contiguous()
+                _lib.check(lib.mirx_stem_conv7_bn_relu_pool(_ptr(x), _ptr(wt), _ptr(sc), _ptr(sh), b, h, w,
+                                                            _ptr(y), _stream(x.device)), "mirx_stem")
             x = y
         else:
             x = f.pool0(f.relu0(f.norm0(f.conv0(x))))

@@ -312,6 +312,15 @@ int mirx_stem_conv7_bn_relu_pool(const float *x, const float *w, const float *sc
                                  void *stream);
 
 /*
+ * The same stem with the implicit GEMM on three-term bf16 MFMAs (fp32-grade, see mirx_conv1x1_bn_relu_split3).
+ * w3 = device bf16 [2 blocks of 32 oc][11 steps][3 terms][32 oc][16 k]: step s, k = 8 g + i is weight
+ * (c, ky) = divmod(2 s + g, 7), kx = 2 i for i < 4, 2 (i - 4) + 1 for i >= 4 (kx = 7 and row 21 are zero)
+ * -- mirx.model._stem_weights_split3(conv0.weight).  n <= 65535.
+ */
+int mirx_stem_conv7_bn_relu_pool_split3(const float *x, const void *w3, const float *scale, const float *shift,
+                                        int64_t n, int h, int wd, float *y, void *stream);
+
+/*
  * Fused 1x1 convolution of a DenseNet dense layer / transition (fp32 MFMA):
  *     y[b, o, p] = act_out( sum_k wt[k, o] * act_in(x[b, k, p]) + bias[o] )
  * act_in(v) = relu(v * scale[k] + shift[k]) when scale != NULL (norm1 + relu1), identity otherwise;

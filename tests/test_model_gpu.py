@@ -39,6 +39,18 @@ def test_stem_kernel(model_and_sd):
         assert rc == 0
         torch.cuda.synchronize()
         torch.testing.assert_close(y.cpu(), ref, atol=2e-4, rtol=1e-4)
+        # the three-term bf16 MFMA variant: same map, within 2e-6 of the fp32-MFMA kernel (relative to its maximum)
+        from mirx.model import _stem_weights_split3
+        w3 = _stem_weights_split3(f.conv0.weight)
+        assert w3.shape == (2, 11, 3, 32, 16) and w3.dtype == torch.bfloat16
+        y3 = torch.full_like(y, float("nan"))
+        rc = lib.mirx_stem_conv7_bn_relu_pool_split3(ctypes.c_void_p(xg.data_ptr()), ctypes.c_void_p(w3.data_ptr()),
+                                                     ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(sh.data_ptr()),
+                                                     b, h, w, ctypes.c_void_p(y3.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        torch.testing.assert_close(y3.cpu(), ref, atol=2e-4, rtol=1e-4)
+        assert float((y3 - y).abs().max()) < 2e-6 * float(y.abs().max())
 
 
 def test_head_kernel():
