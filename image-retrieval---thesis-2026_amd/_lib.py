@@ -61,6 +61,7 @@ SYMBOLS = {
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
+    "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_attention_qkv_f32": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_attention_qkv_f32_split3": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),

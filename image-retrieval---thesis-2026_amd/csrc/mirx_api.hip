@@ -703,6 +703,17 @@ int mirx_conv3x3_winograd_split3_nchw(const float *x, const void *u3, int64_t n,
     return MIRX_OK;
 }
 
+int mirx_conv3x3_direct_split3_nchw(const float *x, const void *w3, int64_t n, int side, float *out,
+                                    int64_t out_batch_stride, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_direct: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_direct: side must be 56, 28 or 14");
+    MIRX_CHECK(n == 0 || (x && w3 && out), "conv3x3_direct: null buffer");
+    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_direct: output batch stride too small");
+    MIRX_HIP(launch_conv3x3_d3(x, reinterpret_cast<const uint16_t *>(w3), n, side, out, out_batch_stride,
+                               reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
                            float *out, void *stream) {
     MIRX_CHECK(batch >= 0 && n_tokens >= 0 && heads >= 1, "attention: bad sizes");

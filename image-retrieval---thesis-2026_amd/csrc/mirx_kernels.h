@@ -77,6 +77,10 @@ hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int si
 // ---- k_conv3x3_s3.hip: the same convolution on three-term bf16 MFMAs (side 56 / 28 / 14) ----------
 hipError_t launch_conv3x3_wino_s3(const float *x, const uint16_t *u3, int64_t n, int side, float *out, int64_t out_bs,
                                   hipStream_t st);
+// ---- k_conv3x3_d3.hip: the same convolution as a direct implicit GEMM on three-term bf16 MFMAs ------
+// w3 = [8 stages][9 taps][3 terms][32 oc][16 c] bf16
+hipError_t launch_conv3x3_d3(const float *x, const uint16_t *w3, int64_t n, int side, float *out, int64_t out_bs,
+                             hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

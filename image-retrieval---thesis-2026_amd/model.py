@@ -137,11 +137,16 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
                            "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
             if use_hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
-                # Winograd F(2x2,3x3), written straight into this layer's slice of the buffer: three-term bf16
-                # MFMAs on the 28 / 14 maps (8-11 % faster there), fp32 MFMAs on the 56 (3 % slower with the split:
-                # operand delivery, not the matrix pipe, bounds it) and 7 x 7 maps
+                # written straight into this layer's slice of the buffer.  Per map side (measured, 1024 images):
+                # 56: Winograd F(2x2,3x3) on fp32 MFMAs (1.37 ms; the bf16 variants are operand-delivery bound there);
+                # 28: Winograd on three-term bf16 MFMAs (0.32 vs 0.35 ms); 14: direct implicit GEMM on three-term
+                # bf16 MFMAs (0.078 vs 0.090 / 0.097 ms); 7: Winograd fp32, two images per workgroup
                 dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
-                if h in SPLIT3_CONV3X3:
+                kind = CONV3X3_KERNEL.get(h, "wino")
+                if kind == "direct3":
+                    _lib.check(lib.mirx_conv3x3_direct_split3_nchw(_ptr(y), _ptr(u3[2]), b, h, dst, block.cout * h * w,
+                                                                   _stream(x.device)), "mirx_conv3x3_direct_split3_nchw")
+                elif kind == "wino3":
                     _lib.check(lib.mirx_conv3x3_winograd_split3_nchw(_ptr(y), _ptr(u3[1]), b, h, dst, block.cout * h * w,
                                                                      _stream(x.device)),
                                "mirx_conv3x3_winograd_split3_nchw")
@@ -257,6 +262,18 @@ def _winograd_weights_split3(w):
     return t.permute(2, 4, 0, 1, 3).contiguous()
 
 
+def _conv3x3_weights_split3(w):
+    """conv2 weights [32, 128, 3, 3] -> the three bf16 terms laid out for mirx_conv3x3_direct_split3_nchw:
+    [stage = c // 16][tap = 3 ky + kx][term][oc][c % 16] bf16."""
+    w = w.detach().float()
+    h = w.to(torch.bfloat16)
+    m = (w - h.float()).to(torch.bfloat16)
+    lo = (w - h.float() - m.float()).to(torch.bfloat16)
+    oc, cin = w.shape[0], w.shape[1]
+    t = torch.stack([h, m, lo], 0).reshape(3, oc, cin // 16, 16, 9)        # [term, oc, stage, c % 16, tap]
+    return t.permute(2, 4, 0, 1, 3).contiguous()
+
+
 def _stem_weights_split3(w):
     """conv0 weights [64, 3, 7, 7] -> the three bf16 terms laid out for mirx_stem_conv7_bn_relu_pool_split3:
     [2 oc blocks][11 steps][term][32 oc][16 k]; k = 8 g + i of step s is row (c, ky) = divmod(2 s + g, 7) and
@@ -303,7 +320,7 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-SPLIT3_CONV3X3 = (28, 14)   # map sides whose dense-layer 3x3 convs run the Winograd GEMMs on three-term bf16 MFMAs
+CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # head_dim-64 attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
@@ -470,7 +487,8 @@ class DenseNet121(nn.Module):
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
                     w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
                     blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t,
-                                  (_winograd_weights(layer.conv2.weight), _winograd_weights_split3(layer.conv2.weight)),
+                                  (_winograd_weights(layer.conv2.weight), _winograd_weights_split3(layer.conv2.weight),
+                                   _conv3x3_weights_split3(layer.conv2.weight)),
                                   _split3_weights(w1.view(w1.shape[0], w1.shape[1])))
                 cache[name] = blk
             elif name.startswith("transition"):

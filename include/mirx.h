@@ -227,6 +227,15 @@ int mirx_conv3x3_winograd_split3_nchw(const float *x, const void *u3, int64_t n,
                                       int64_t out_batch_stride, void *stream);
 
 /*
+ * The same convolution (conv2 of a dense layer: 128 -> 32 channels, 3x3, pad 1) as a DIRECT implicit GEMM on
+ * three-term bf16 MFMAs (no Winograd transform: K = 9 taps x 128 channels; fp32-grade): same x / out /
+ * out_batch_stride; w3 = device bf16 [8 stages][9 taps = 3 ky + kx][3 terms][32 oc][16 channels]
+ * (mirx.model._conv3x3_weights_split3).  side in {56, 28, 14}.
+ */
+int mirx_conv3x3_direct_split3_nchw(const float *x, const void *w3, int64_t n, int side, float *out,
+                                    int64_t out_batch_stride, void *stream);
+
+/*
  * Multi-head self-attention of the ViT backbones, fp32: out = softmax(q k^T * scale) v per (image,
  * head), scores never materialised.  Replaces the attention of timm's `vit_base_patch14_dinov2`
  * blocks (model.py:459-463; nih_multilabel_retrieval.py:175-221).  qkv: device [batch, n_tokens, 3,

@@ -225,6 +225,35 @@ def test_winograd_split3_conv3x3_matches_direct_conv(side, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side,batch", [(56, 3), (28, 5), (14, 9), (14, 1)])
+def test_direct_split3_conv3x3_matches_direct_conv(side, batch):
+    """mirx_conv3x3_direct_split3_nchw (implicit GEMM over 9 taps x 128 channels on three-term bf16 MFMAs) against a
+    float64 direct convolution: 3e-6 of the largest output (no Winograd transform error: tighter than the Winograd
+    kernels' 2e-5), written into a channel slice of a wider buffer."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _conv3x3_weights_split3
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side + 200)
+    x = torch.relu(torch.randn(batch, 128, side, side, generator=g, device=dev)) * 1.7
+    w = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    buf = torch.full((batch, 96, side, side), 7.0, device=dev)
+    c0 = 40
+    w3 = _conv3x3_weights_split3(w)
+    assert w3.shape == (8, 9, 3, 32, 16) and w3.dtype == torch.bfloat16
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    _lib.check(lib.mirx_conv3x3_direct_split3_nchw(vp(x), vp(w3), batch, side, vp(buf, 4 * c0 * side * side),
+                                                   96 * side * side, None), "conv3x3_direct")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    got = buf[:, c0:c0 + 32].double().cpu()
+    assert float((got - want).abs().max()) < 3e-6 * float(want.abs().max())
+    assert bool((buf[:, :c0] == 7.0).all()) and bool((buf[:, c0 + 32:] == 7.0).all())      # neighbours untouched
+    assert lib.mirx_conv3x3_direct_split3_nchw(vp(x), vp(w3), batch, 7, vp(buf), 96 * side * side, None) == -1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(256, 256), (160, 192), (112, 112)])
 def test_embeddings_at_other_resolutions(model_and_sd, size):
     """Inputs whose feature maps are not 56/28/14/7 (the reference resizes to 224, read_data.py, but the
