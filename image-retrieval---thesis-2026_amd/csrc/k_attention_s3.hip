@@ -11,8 +11,8 @@
 // first GEMM hands lane (q, h) the keys  kappa(r, h) = 8 (r >> 2) + (r & 3) + 4 h,  r = 0..15; the second GEMM
 // contracts the keys in exactly that order -- step s, k-group h, element i  <->  key kappa(8 s + i, h) -- so P
 // never moves between lanes, and V^T is stored with its key axis permuted to match (position 16 s + 8 h + i).
-// LDS rows: K planes [32 keys][64 ch] bf16 (128 B rows, 16-byte chunk c at c ^ (key & 7)); V^T planes
-// [64 d][32 positions] bf16 (64 B rows, chunk c at c ^ ((d >> 1) & 3)): conflict-free ds_read_b128.
+// LDS rows: K planes [32 keys][64 ch] bf16 (128 B rows, 16-byte chunk c at c ^ ((key >> 1) & 7)); V^T planes
+// [64 d][32 positions] bf16 (64 B rows, chunk c at c ^ ((d >> 2) & 3)): the chunk index changes every 256 bytes.
 // head_dim 64 (ViT-B / DINOv2).
 #include "mirx_kernels.h"
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void k_attention_s3(const float *__restrict
     // K: thread -> key t >> 3, channels 8 (t & 7) .. + 7 (two float4)        -> one 16-byte chunk per term
     // V: thread -> keys 2 (t >> 4), 2 (t >> 4) + 1, channels 4 (t & 15) .. + 3  -> four bf16 pairs per term
     const int kk = threadIdx.x >> 3, kc = threadIdx.x & 7;
-    const int k_lds = kk * 128 + ((kc ^ (kk & 7)) << 4);                   // + term * K_PLANE
+    const int k_lds = kk * 128 + ((kc ^ ((kk >> 1) & 7)) << 4);                   // + term * K_PLANE
     const int vm_ = threadIdx.x >> 4, vc = threadIdx.x & 15;
     const int vkey = 2 * vm_;
     // position of key k on the permuted axis: 16 (k >> 4) + 8 ((k >> 2) & 1) + (k & 3) + 4 ((k >> 3) & 1)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 3) void k_attention_s3(const float *__restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int d = 4 * vc + j;
-        v_lds[j] = 3 * K_PLANE + d * 64 + ((((vpos >> 3) ^ ((d >> 1) & 3))) << 4) + (vpos & 7) * 2;   // + term * V_PLANE
+        v_lds[j] = 3 * K_PLANE + d * 64 + ((((vpos >> 3) ^ ((d >> 2) & 3))) << 4) + (vpos & 7) * 2;   // + term * V_PLANE
     }
     f32x4 rk[2], rv[2];
     auto load_tile = [&](int kt) {
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(256, 3) void k_attention_s3(const float *__restrict
     // fragment addresses: K row nq (key), chunk 2 ks + half; V^T row 32 t + nq (d), chunk 2 s + half
     int fk[4], fv[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fk[ks] = nq * 128 + (((2 * ks + half) ^ (nq & 7)) << 4);
+    for (int ks = 0; ks < 4; ++ks) fk[ks] = nq * 128 + (((2 * ks + half) ^ ((nq >> 1) & 7)) << 4);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int d = 32 * t + nq;
-            fv[t][s] = 3 * K_PLANE + d * 64 + (((2 * s + half) ^ ((d >> 1) & 3)) << 4);
+            fv[t][s] = 3 * K_PLANE + d * 64 + (((2 * s + half) ^ ((d >> 2) & 3)) << 4);
         }
 
     f32x16 o[2];

@@ -14,8 +14,10 @@
 // image = 7 column blocks of 32 pixels (waves 0..2 take two, wave 3 one) x all 32 output channels.
 //   * X: 16-channel stages; the padded strip ((R + 2) x (W + 2) pixels) is split into its three bf16 terms while it
 //     is staged and stored pixel-major -- [term][padded pixel][16 channels] bf16, the two 16-byte halves of a pixel
-//     at slot h ^ ((pixel >> 2) & 1) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
-//     ds_read_b128 per term, conflict-free for 8 consecutive pixels.  Double-buffered, register-prefetched.
+//     at slot h ^ ((pixel >> 3) & 1), i.e. the slot flips every 256 bytes (the pattern that measures zero
+//     SQ_LDS_BANK_CONFLICT for 16-byte reads on gfx950; flipping every 128 bytes measured 0.5 conflict cycles per
+//     active cycle) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
+//     ds_read_b128 per term.  Double-buffered, register-prefetched.
 //   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][3 terms][32 oc][16 c] bf16,
 //     mirx.model._conv3x3_weights_split3); a lane reads its 16-byte A fragments straight from global memory (221 KiB
 //     per layer, L2-resident): taps 0..3 at the end of the previous stage, taps 4..8 two taps ahead of their use.
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d3(const float *__restrict__
         inside[i] = live && iy >= 0 && iy < W && ix >= 0 && ix < W;
         const int cy = iy < 0 ? 0 : (iy >= W ? W - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
         g_off[i] = (8 * hh * W + cy) * W + cx;                // + (stage * 16 + j) * W * W
-        l_off[i] = live ? pix * 32 + ((hh ^ ((pix >> 2) & 1)) << 4) : -1;
+        l_off[i] = live ? pix * 32 + ((hh ^ ((pix >> 3) & 1)) << 4) : -1;
     }
     auto load = [&](int st) {
 #pragma unroll
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d3(const float *__restrict__
 #define MIRX_D3_READB(DST, TAP, T)                                                                 \
     {                                                                                              \
         const int pix_ = pbase[T] + ((TAP) / 3) * PW + (TAP) % 3;                                  \
-        const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 2) & 1)) << 4);                      \
+        const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 3) & 1)) << 4);                      \
         DST[0] = *reinterpret_cast<const bf16x8 *>(pb_);                                           \
         DST[1] = *reinterpret_cast<const bf16x8 *>(pb_ + PLANE);                                   \
         DST[2] = *reinterpret_cast<const bf16x8 *>(pb_ + 2 * PLANE);                               \
