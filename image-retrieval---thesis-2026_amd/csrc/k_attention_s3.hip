@@ -13,7 +13,7 @@
 // never moves between lanes, and V^T is stored with its key axis permuted to match (position 16 s + 8 h + i).
 // LDS rows: K planes [32 keys][64 ch] bf16 (128 B rows, 16-byte chunk c at c ^ ((key >> 1) & 7)); V^T planes
 // [64 d][32 positions] bf16 (64 B rows, chunk c at c ^ ((d >> 2) & 3)): the chunk index changes every 256 bytes.
-// head_dim 64 (ViT-B / DINOv2).
+// k_attention_s3: head_dim 64 (ViT-B / DINOv2); k_attention_s3g<DH>: 32 / 72 / 96.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -245,12 +245,250 @@ __global__ __launch_bounds__(256, 3) void k_attention_s3(const float *__restrict
     }
 }
 
+// ---- any head_dim that is a multiple of 8 (72: the SigLIP-So400m tower) --------------------------------------------
+// Same algorithm; what changes against the head_dim-64 kernel above: the K rows hold KS = ceil(DH / 16) MFMA steps
+// (channels beyond DH are zero in Q and K), their 16-byte chunks are rotated by key >> 2 instead of XORed (the
+// chunk count is not a power of two); the output has NT = ceil(DH / 32) tiles, the lanes of a partly filled last
+// tile re-read row DH - 1 of V^T and their results are dropped; staging walks item lists (K: key x chunk, V: key
+// pair x 4 channels) because they no longer divide by 256 threads.
+template <int DH>
+__global__ __launch_bounds__(256, 2) void k_attention_s3g(const float *__restrict__ qkv, int n, int heads,
+                                                          float scale_log2e, float *__restrict__ out) {
+    constexpr int KS = (DH + 15) / 16, KCH = 2 * KS, KROW = KCH * 16;      // K row: KCH chunks of 16 B
+    constexpr int NT = (DH + 31) / 32;
+    constexpr int KPL = KT * KROW, VPL = DH * 64, GBUF = 3 * (KPL + VPL);
+    extern __shared__ __attribute__((aligned(16))) char smg[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, nq = lane & 31;
+    const int head = blockIdx.y;
+    const int64_t img = blockIdx.z;
+    const int64_t tok = 3 * (int64_t)heads * DH;
+    const float *base = qkv + img * n * tok + head * DH;
+    const int q_idx = blockIdx.x * 128 + wave * 32 + nq;
+    const int q_ld = q_idx < n ? q_idx : n - 1;
+
+    bf16x8 qh[KS], qm[KS], ql[KS];
+    {
+        const float *qp = base + q_ld * tok;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 16 * ks + 8 * half;                             // DH % 8 == 0: a chunk is all in or all out
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (c0 < DH) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(qp + c0), b = *reinterpret_cast<const f32x4 *>(qp + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = a[j] * scale_log2e; v[4 + j] = b[j] * scale_log2e; }
+            }
+            split8(v, qh[ks], qm[ks], ql[ks]);
+        }
+    }
+
+    // ---- staging item lists ----------------------------------------------------------------------------------------
+    constexpr int NKI = KT * KCH, IPK = (NKI + 255) / 256;                // K items: (key, chunk of 8 channels)
+    constexpr int NVI = (KT / 2) * (DH / 4), IPV = (NVI + 255) / 256;     // V items: (key pair, 4 channels)
+    f32x4 rk[IPK][2], rv[IPV][2];
+    auto k_item = [&](int i, int &key, int &c, bool &live) {
+        int it = threadIdx.x + 256 * i;
+        live = it < NKI;
+        if (!live) it = NKI - 1;
+        key = it / KCH;
+        c = it % KCH;
+    };
+    auto v_item = [&](int i, int &m, int &vc, bool &live) {
+        int it = threadIdx.x + 256 * i;
+        live = it < NVI;
+        if (!live) it = NVI - 1;
+        m = it / (DH / 4);
+        vc = it % (DH / 4);
+    };
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < IPK; ++i) {
+            int key, c; bool live;
+            k_item(i, key, c, live);
+            int g = kt * KT + key;
+            if (g >= n) g = n - 1;
+            const int cc = 8 * c < DH ? 8 * c : DH - 8;                    // pad chunk: read something valid, store zeros
+            const float *kp = base + g * tok + heads * DH + cc;
+            rk[i][0] = *reinterpret_cast<const f32x4 *>(kp);
+            rk[i][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < IPV; ++i) {
+            int m, vc; bool live;
+            v_item(i, m, vc, live);
+            int k0 = kt * KT + 2 * m, k1 = k0 + 1;
+            if (k0 >= n) k0 = n - 1;
+            if (k1 >= n) k1 = n - 1;
+            rv[i][0] = *reinterpret_cast<const f32x4 *>(base + k0 * tok + 2 * heads * DH + 4 * vc);
+            rv[i][1] = *reinterpret_cast<const f32x4 *>(base + k1 * tok + 2 * heads * DH + 4 * vc);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *sb = smg + buf * GBUF;
+#pragma unroll
+        for (int i = 0; i < IPK; ++i) {
+            int key, c; bool live;
+            k_item(i, key, c, live);
+            const bool real = 8 * c < DH;
+            u32x4 ph, pm, pl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned th, tm, tl;
+                split2(real ? rk[i][p >> 1][2 * (p & 1)] : 0.f, real ? rk[i][p >> 1][2 * (p & 1) + 1] : 0.f, th, tm, tl);
+                ph[p] = th; pm[p] = tm; pl[p] = tl;
+            }
+            if (live) {
+                const int pos = (c + (key >> 2)) % KCH;
+                char *d = sb + key * KROW + pos * 16;
+                *reinterpret_cast<u32x4 *>(d) = ph;
+                *reinterpret_cast<u32x4 *>(d + KPL) = pm;
+                *reinterpret_cast<u32x4 *>(d + 2 * KPL) = pl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IPV; ++i) {
+            int m, vc; bool live;
+            v_item(i, m, vc, live);
+            const int vkey = 2 * m;
+            const int vpos = 16 * (vkey >> 4) + 8 * ((vkey >> 2) & 1) + (vkey & 3) + 4 * ((vkey >> 3) & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned th, tm, tl;
+                split2(rv[i][0][j], rv[i][1][j], th, tm, tl);
+                const int d = 4 * vc + j;
+                char *dst = sb + 3 * KPL + d * 64 + (((vpos >> 3) ^ ((d >> 2) & 3)) << 4) + (vpos & 7) * 2;
+                if (live) {
+                    *reinterpret_cast<unsigned *>(dst) = th;
+                    *reinterpret_cast<unsigned *>(dst + VPL) = tm;
+                    *reinterpret_cast<unsigned *>(dst + 2 * VPL) = tl;
+                }
+            }
+        }
+    };
+
+    int fk[KS], fv[NT][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int pos = (2 * ks + half + (nq >> 2)) % KCH;
+        fk[ks] = nq * KROW + pos * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int d = 32 * t + nq < DH ? 32 * t + nq : DH - 1;
+            fv[t][s] = 3 * KPL + d * 64 + (((2 * s + half) ^ ((d >> 2) & 3)) << 4);
+        }
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = (n + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();
+        load_tile(kt + 1 < ntiles ? kt + 1 : kt);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = smg + cur * GBUF;
+
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fk[ks]);
+            const bf16x8 am = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + KPL);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + 2 * KPL);
+            MIRX_MFMA6(sacc, ah, am, al, qh[ks], qm[ks], ql[ks])
+        }
+
+        const int key0 = kt * KT + 4 * half;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + (r & 3);
+            if (key >= n) sacc[r] = -INFINITY;
+            mt = fmaxf(mt, sacc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = exp2f(sacc[r] - m_new);
+            psum += sacc[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float pv[8] = {sacc[8 * s], sacc[8 * s + 1], sacc[8 * s + 2], sacc[8 * s + 3],
+                                 sacc[8 * s + 4], sacc[8 * s + 5], sacc[8 * s + 6], sacc[8 * s + 7]};
+            bf16x8 bh, bm, bl;
+            split8(pv, bh, bm, bl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s]);
+                const bf16x8 am = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s] + VPL);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s] + 2 * VPL);
+                MIRX_MFMA6(o[t], ah, am, al, bh, bm, bl)
+            }
+        }
+        store_tile(cur ^ 1);
+    }
+
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q_idx < n) {
+        const float inv = 1.0f / l_run;
+        float *op = out + ((img * n + q_idx) * heads + head) * DH + 4 * half;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * t + 8 * g + 4 * half >= DH) continue;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
+                *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
+template <int DH>
+hipError_t launch_s3g(const float *qkv, int64_t batch, int n, int heads, float scale, float *out, hipStream_t st) {
+    constexpr int KS = (DH + 15) / 16;
+    const size_t lds = (size_t)2 * 3 * (KT * KS * 32 + DH * 64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_s3g<DH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(k_attention_s3g<DH>, grid, dim3(256), lds, st, qkv, n, heads, scale * 1.4426950408889634f, out);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_attention_s3(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                                hipStream_t st) {
     if (batch <= 0 || n <= 0) return hipSuccess;
-    if (head_dim != DH || heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (head_dim == 72) return launch_s3g<72>(qkv, batch, n, heads, scale, out, st);
+    if (head_dim == 96) return launch_s3g<96>(qkv, batch, n, heads, scale, out, st);
+    if (head_dim == 32) return launch_s3g<32>(qkv, batch, n, heads, scale, out, st);
+    if (head_dim != DH) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
     hipLaunchKernelGGL(k_attention_s3, grid, dim3(256), 0, st, qkv, n, heads, scale * 1.4426950408889634f, out);
     return hipGetLastError();

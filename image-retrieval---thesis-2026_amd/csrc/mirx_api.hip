@@ -728,7 +728,8 @@ int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int he
 int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
                                   float *out, void *stream) {
     MIRX_CHECK(batch >= 0 && n_tokens >= 0 && heads >= 1, "attention_split3: bad sizes");
-    MIRX_CHECK(head_dim == 64, "attention_split3: head_dim must be 64");
+    MIRX_CHECK(head_dim == 32 || head_dim == 64 || head_dim == 72 || head_dim == 96,
+               "attention_split3: head_dim must be 32, 64, 72 or 96");
     MIRX_CHECK(batch <= 65535 && heads <= 65535, "attention_split3: batch and heads must be <= 65535");
     MIRX_CHECK(batch == 0 || n_tokens == 0 || (qkv && out), "attention_split3: null buffer");
     MIRX_HIP(launch_attention_s3(qkv, batch, n_tokens, heads, head_dim, scale, out, reinterpret_cast<hipStream_t>(stream)));

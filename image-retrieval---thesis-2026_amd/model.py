@@ -322,7 +322,7 @@ def _stream(dev):
 
 CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
-SPLIT3_ATTENTION = True  # head_dim-64 attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
+SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
 
 
@@ -396,9 +396,10 @@ def _route_tower_attention(root):
                     qkv = _linear_s3(_p, x)
                     a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
                     with torch.cuda.device(x.device):
-                        _lib.check(_lib.load().mirx_attention_qkv_f32(_ptr(qkv), b, n, c // _m.head_dim, _m.head_dim,
-                                                                      float(_m.scale), _ptr(a), _stream(x.device)),
-                                   "mirx_attention_qkv_f32")
+                        lib = _lib.load()
+                        att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                        _lib.check(att(_ptr(qkv), b, n, c // _m.head_dim, _m.head_dim, float(_m.scale), _ptr(a),
+                                       _stream(x.device)), "mirx_attention_qkv_f32")
                     return _m.out_proj(a), None
                 return _orig(hidden_states, attention_mask, **kw)
 
@@ -755,7 +756,7 @@ class _VitAttention(nn.Module):
         b, n, c = x.shape
         dh = c // self.num_heads
         qkv = self.qkv(x)                                                # [b, n, 3, heads, dh] packed
-        if x.is_cuda and dh == 64 and qkv.dtype == torch.float32 and not torch.is_grad_enabled():
+        if x.is_cuda and dh in (32, 64, 72, 96) and qkv.dtype == torch.float32 and not torch.is_grad_enabled():
             # MI355X inference path: fp32 MFMA flash attention straight on the packed projection,
             # output already [b, n, heads * dh] (include/mirx.h: mirx_attention_qkv_f32)
             qkv = qkv.contiguous()

@@ -248,8 +248,7 @@ int mirx_attention_qkv_f32(const float *qkv, int64_t batch, int n_tokens, int he
 
 /*
  * mirx_attention_qkv_f32 with both GEMMs on three-term bf16 MFMAs (Q, K, V and the probabilities each carried
- * as xh + xm + xl; fp32-grade, see mirx_conv1x1_bn_relu_split3): same arguments and result layout.
- * head_dim must be 64.
+ * as xh + xm + xl; fp32-grade, see mirx_conv1x1_bn_relu_split3): same arguments, result layout and head_dim set.
  */
 int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
                                   float scale, float *out, void *stream);

@@ -42,12 +42,13 @@ def test_attention_matches_float64(b, n, heads, dh):
 
 @pytest.mark.parametrize("b,n,heads", [(1, 1, 1), (2, 5, 3), (1, 32, 2), (1, 33, 1), (3, 127, 2), (2, 128, 12),
                                        (1, 129, 1), (2, 257, 12), (1, 1370, 12)])
-def test_attention_split3_matches_float64(b, n, heads):
+@pytest.mark.parametrize("dh", [64, 72])
+def test_attention_split3_matches_float64(b, n, heads, dh):
     """mirx_attention_qkv_f32_split3: both GEMMs on three-term bf16 MFMAs; same tolerance as the fp32 kernel, and
-    a peaked case (logits ~ +-60)."""
+    a peaked case (logits ~ +-60).  head_dim 64 = the tuned kernel, 72 = the generic one."""
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1000 * n + heads + 7)
-    qkv = torch.randn((b, n, 3, heads, 64), generator=g, device=dev) * 1.5
+    qkv = torch.randn((b, n, 3, heads, dh), generator=g, device=dev) * 1.5
     out = _run(qkv, heads, split3=True)
     ref = _ref(qkv)
     assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
@@ -66,9 +67,10 @@ def test_attention_other_head_dims(dh):
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(dh)
     qkv = torch.randn((2, 77, 3, 3, dh), generator=g, device=dev)
-    out = _run(qkv, 3)
     ref = _ref(qkv)
-    assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+    for split3 in (False, True):
+        out = _run(qkv, 3, split3=split3)
+        assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
 
 
 def test_attention_peaked_and_large_logits():
