@@ -56,7 +56,7 @@ SYMBOLS = {
     "mirx_rank_metrics": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _int, _int, ctypes.c_double, _int,
                                  ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp, _vp, _vp, _vp]),
     "mirx_linear_split3": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
-    "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
+    "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),

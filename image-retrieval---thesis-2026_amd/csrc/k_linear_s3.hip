@@ -44,7 +44,7 @@ constexpr int KC = 16;             // features per stage
 constexpr int PLANE = 128 * KC * 2;            // bytes of one term of one operand stage (4 KiB)
 constexpr int STAGE = 6 * PLANE;               // x terms [0, 3), w terms [3, 6): 24 KiB
 
-template <int ACT, bool RES, bool NCHW>
+template <int ACT, bool RES, bool NCHW, bool GRN>
 __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ x, int64_t m, int k,
                                                       const uint16_t *__restrict__ w3,
                                                       const float *__restrict__ bias, int n, const float *res,
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
 
     f32x4 rx[2], rx2[2];
+    // GRN (ConvNeXt block tail): x is multiplied by the per-(image, feature) scale `gamma` = [m / tpi][k] while it is
+    // staged -- the GRN apply pass over the 4C-wide hidden map disappears (its shift is folded into the bias by the
+    // caller: W (x s + b) = W (x s) + W b)
+    f32x4 sx[2], sx2[2];
+    const float *gsp = GRN ? gamma + (xr / tpi) * k + 8 * x_half : nullptr;
     auto dma_w = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -82,16 +87,24 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
                                                      w_voff, kt * (3 * TN * KC * 2) + piece * 1024, 0, 0);
         }
     };
-    auto load_x = [&](int kt, f32x4 (&r)[2]) {
+    auto load_x = [&](int kt, f32x4 (&r)[2], f32x4 (&sc)[2]) {
         r[0] = *reinterpret_cast<const f32x4 *>(xsrc + kt * KC);
         r[1] = *reinterpret_cast<const f32x4 *>(xsrc + kt * KC + 4);
+        if (GRN) {
+            sc[0] = *reinterpret_cast<const f32x4 *>(gsp + kt * KC);
+            sc[1] = *reinterpret_cast<const f32x4 *>(gsp + kt * KC + 4);
+        }
     };
-    auto store_x = [&](int buf, const f32x4 (&r)[2]) {
+    auto store_x = [&](int buf, const f32x4 (&r)[2], const f32x4 (&sc)[2]) {
         char *sb = sm + buf * STAGE;
         u32x4 ph, pm, pl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x2 v = {r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
+            f32x2 v = {r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
+            if (GRN) {
+                v[0] *= sc[j >> 1][2 * (j & 1)];
+                v[1] *= sc[j >> 1][2 * (j & 1) + 1];
+            }
             const bf16x2 h = __builtin_convertvector(v, bf16x2);
             const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
             const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
@@ -159,9 +172,9 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
     // (16 features = 64 B per token row per stage), so both are issued together while the line is in the
     // vector L1; issued a stage apart, the second half comes from L2 again.
     dma_w(0, 0);
-    load_x(0, rx);
-    load_x(nk > 1 ? 1 : 0, rx2);
-    store_x(0, rx);
+    load_x(0, rx, sx);
+    load_x(nk > 1 ? 1 : 0, rx2, sx2);
+    store_x(0, rx, sx);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         // ---- even stage kt in buffer 0; registers: rx2 = x of stage kt + 1 -------------------------------
@@ -169,16 +182,16 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
         dma_w(kt + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_stage(0);
-        store_x(1, rx2);
+        store_x(1, rx2, sx2);
         // ---- odd stage kt + 1 in buffer 1; loads the x of BOTH stages of the next pair -------------------
         STAGE_BARRIER();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1, k3 = kt + 3 < nk ? kt + 3 : nk - 1;   // branch-free tail
         dma_w(k2, 0);
-        load_x(k2, rx);
-        load_x(k3, rx2);
+        load_x(k2, rx, sx);
+        load_x(k3, rx2, sx2);
         __builtin_amdgcn_sched_barrier(0);
         mfma_stage(1);
-        store_x(0, rx);
+        store_x(0, rx, sx);
     }
     if (kt < nk) {                                         // odd stage count: the last stage sits in buffer 0
         STAGE_BARRIER();
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
                     float v = acc[mi][ni][r] + (bias ? bias[col] : 0.f);
                     if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     const int64_t idx = base + (int64_t)col * tpi;
-                    if (RES) v = res[idx] + ((RES && gamma) ? gamma[col] : 1.f) * v;
+                    if (RES) v = res[idx] + v;
                     y[idx] = v;
                 }
         }
@@ -243,21 +256,25 @@ hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3
     if (per_xcd * 8 > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(per_xcd * 8));
     const size_t lds = 2 * (size_t)STAGE;
-#define MIRX_L3(A, R, C)                                                                                   \
+#define MIRX_L3(A, R, C, G)                                                                                \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_s3<A, R, C>),           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_s3<A, R, C, G>),        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_linear_s3<A, R, C>), grid, dim3(256), lds, st, x, m, k, w3, bias, n, res, gamma, y, \
+        hipLaunchKernelGGL((k_linear_s3<A, R, C, G>), grid, dim3(256), lds, st, x, m, k, w3, bias, n, res, gamma, y, \
                            ntn, total, per_xcd, tokens_per_image);                                         \
     }
-    if (tokens_per_image > 0) {                       // ConvNeXt block tail: no activation variant needed
+    if (tokens_per_image > 0) {                       // ConvNeXt block tail: `gamma` = GRN input scale [images][k] or null
         if (act) return hipErrorInvalidValue;
-        if (res) MIRX_L3(0, true, true) else MIRX_L3(0, false, true)
+        if (gamma) {
+            if (res) MIRX_L3(0, true, true, true) else MIRX_L3(0, false, true, true)
+        } else {
+            if (res) MIRX_L3(0, true, true, false) else MIRX_L3(0, false, true, false)
+        }
     } else if (res) {
-        if (act) MIRX_L3(1, true, false) else MIRX_L3(0, true, false)
+        if (act) MIRX_L3(1, true, false, false) else MIRX_L3(0, true, false, false)
     } else {
-        if (act) MIRX_L3(1, false, false) else MIRX_L3(0, false, false)
+        if (act) MIRX_L3(1, false, false, false) else MIRX_L3(0, false, false, false)
     }
 #undef MIRX_L3
     return hipGetLastError();

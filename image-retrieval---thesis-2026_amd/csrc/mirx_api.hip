@@ -659,13 +659,15 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
 }
 
 int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
-                            const float *bias_or_null, int n, const float *residual_or_null, float *y, void *stream) {
+                            const float *bias_or_null, int n, const float *residual_or_null,
+                            const float *input_scale_or_null, float *y, void *stream) {
     MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 1,
                "linear_split3_nchw: k must be a multiple of 16");
     MIRX_CHECK(n_img == 0 || (x && w3 && y), "linear_split3_nchw: null buffer");
     MIRX_CHECK(x != y, "linear_split3_nchw: y may alias the residual, not the input");
     MIRX_HIP(launch_linear_s3(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w3), bias_or_null, n, 0,
-                              residual_or_null, nullptr, y, tokens_per_image, reinterpret_cast<hipStream_t>(stream)));
+                              residual_or_null, input_scale_or_null, y, tokens_per_image,
+                              reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

@@ -188,12 +188,15 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
 /*
  * Tail of a ConvNeXtV2 block (timm ConvNeXtBlock.forward, used by the reference's model.py:87-118): the second
  * point-wise Linear on the channels-last hidden map, written back channels-first with the block's skip added:
- *     y[b, j, p] = residual[b, j, p] + sum_k x[b * tpi + p, k] W[j, k] + bias[j]
+ *     y[b, j, p] = residual[b, j, p] + sum_k (x[b * tpi + p, k] * input_scale[b, k]) W[j, k] + bias[j]
  * x = device fp32 [n_img * tokens_per_image, k]; w3 as in mirx_linear_split3; residual / y = device fp32
  * [n_img, n, tokens_per_image] (NCHW); residual NULL = no skip; y may alias residual.
+ * input_scale = device fp32 [n_img, k] or NULL: the GRN factor 1 + weight * gx / (mean gx + eps), applied while x
+ * is staged (the GRN shift is constant per feature: the caller adds W . grn_bias to `bias`).
  */
 int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
-                            const float *bias_or_null, int n, const float *residual_or_null, float *y, void *stream);
+                            const float *bias_or_null, int n, const float *residual_or_null,
+                            const float *input_scale_or_null, float *y, void *stream);
 
 /*
  * Global response normalisation of ConvNeXtV2 (timm GlobalResponseNorm, channels last) as two HBM passes:

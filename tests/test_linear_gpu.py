@@ -101,8 +101,20 @@ def test_linear_split3_nchw_matches_float64(n_img, tpi, k, n, use_res):
     if use_res:
         want = want + res.double()
     y = torch.full((n_img, n, tpi), float("nan"), device=dev)
-    _lib.check(lib.mirx_linear_split3_nchw(_vp(x), n_img, tpi, k, _vp(_split3_weights(w)), _vp(b), n, _vp(res), _vp(y),
-                                           None), "mirx_linear_split3_nchw")
+    _lib.check(lib.mirx_linear_split3_nchw(_vp(x), n_img, tpi, k, _vp(_split3_weights(w)), _vp(b), n, _vp(res), None,
+                                           _vp(y), None), "mirx_linear_split3_nchw")
+    torch.cuda.synchronize()
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+    # with a per-(image, feature) input scale (the GRN factor folded into the staging)
+    sc = (0.5 + torch.rand(n_img, k, generator=g)).to(dev)
+    xs = (x.double().reshape(n_img, tpi, k) * sc.double()[:, None, :]).reshape(n_img * tpi, k)
+    want = (xs @ w.double().t() + b.double()).reshape(n_img, tpi, n).permute(0, 2, 1)
+    if use_res:
+        want = want + res.double()
+    y = torch.full((n_img, n, tpi), float("nan"), device=dev)
+    _lib.check(lib.mirx_linear_split3_nchw(_vp(x), n_img, tpi, k, _vp(_split3_weights(w)), _vp(b), n, _vp(res), _vp(sc),
+                                           _vp(y), None), "mirx_linear_split3_nchw")
     torch.cuda.synchronize()
     err = float((y.double() - want).abs().max())
     assert err < 3e-6 * max(1.0, float(want.abs().max())), err
