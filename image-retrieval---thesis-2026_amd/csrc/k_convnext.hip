@@ -19,7 +19,7 @@ constexpr int DP = DT + 6;             // input patch edge (22)
 constexpr int DCH = 32;                // channels per workgroup
 constexpr int DPITCH = DP * DP + 1;    // 485
 
-__global__ __launch_bounds__(256) void k_dwconv7(const float *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x, const float *__restrict__ w,
                                                  const float *__restrict__ bias, int c, int h, int wd,
                                                  float *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // [DCH][DPITCH]
@@ -29,12 +29,34 @@ __global__ __launch_bounds__(256) void k_dwconv7(const float *__restrict__ x, co
     const int64_t img = blockIdx.z;
     const int y0 = ty * DT, x0 = tx * DT;
     const float *xi = x + (img * c + c0) * (int64_t)h * wd;
-    for (int i = threadIdx.x; i < DCH * DP * DP; i += 256) {
-        const int ch = i / (DP * DP), r = (i / DP) % DP, q = i % DP;
-        const int yy = y0 + r - 3, xx = x0 + q - 3;
-        float v = 0.0f;
-        if (c0 + ch < c && yy >= 0 && yy < h && xx >= 0 && xx < wd) v = xi[((int64_t)ch * h + yy) * wd + xx];
-        sm[ch * DPITCH + r * DP + q] = v;
+    // The global loads of a thread are issued in batches of 16 before the matching LDS stores (addresses clamped,
+    // values zeroed when they are stored): with a load -> store loop the workgroup paid one HBM latency per element
+    // (61 per thread); one batch of 61 costs more registers than two workgroups per CU can have.
+    constexpr int N_IN = (DCH * DP * DP + 255) / 256;           // 61 per thread
+    constexpr int NB = 16;
+#pragma unroll 1
+    for (int t0 = 0; t0 < N_IN; t0 += NB) {
+        float vin[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            int i = threadIdx.x + 256 * (t0 + t);
+            if (i >= DCH * DP * DP) i = DCH * DP * DP - 1;
+            int ch = i / (DP * DP);
+            const int r = (i / DP) % DP, q = i % DP;
+            int yy = y0 + r - 3, xx = x0 + q - 3;
+            yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= wd ? wd - 1 : xx);
+            if (c0 + ch >= c) ch = c - 1 - c0;
+            vin[t] = xi[((int64_t)ch * h + yy) * wd + xx];
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int i = threadIdx.x + 256 * (t0 + t);
+            const int ch = i / (DP * DP), r = (i / DP) % DP, q = i % DP;
+            const int yy = y0 + r - 3, xx = x0 + q - 3;
+            const bool in = c0 + ch < c && yy >= 0 && yy < h && xx >= 0 && xx < wd;
+            if (i < DCH * DP * DP) sm[ch * DPITCH + r * DP + q] = in ? vin[t] : 0.0f;
+        }
     }
     __syncthreads();
     const int ch = threadIdx.x & 31, rg = threadIdx.x >> 5;        // channel, pair of output rows
