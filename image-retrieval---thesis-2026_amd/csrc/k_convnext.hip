@@ -2,10 +2,10 @@
 // NCHW and written NHWC, i.e. conv_dw + the permute(0, 2, 3, 1) that timm's ConvNeXtBlock does
 // before its LayerNorm / MLP (reference model.py:96-100 -> timm convnextv2_base blocks).
 //
-// HBM-bound: 49 MACs per output against 8 bytes of traffic.  One workgroup = 16 x 16 output
-// pixels x 32 channels of one image: the 22 x 22 input patches of the 32 channels sit in LDS
-// (channel pitch 485 floats: odd, so the 32 lanes of a half-wave -- one per channel -- never
-// collide on a bank); a thread owns one channel and two output rows, keeps that channel's 49
+// 49 MACs per output against 8 bytes of traffic.  One workgroup = 16 x 16 (or 12 x 12) output
+// pixels x 32 channels of one image: the 22 x 22 (18 x 18) input patches of the 32 channels sit in LDS
+// (channel pitch 485 / 325 floats: odd, so the 32 lanes of a half-wave -- one per channel -- never
+// collide on a bank); a thread owns one channel and two (three) output rows, keeps that channel's 49
 // weights in registers, and for every kernel row reads 22 inputs for 7 x 16 FMAs.  The NHWC store
 // puts the 32 channels of a pixel in one 128-byte segment.
 #include "mirx_kernels.h"
@@ -14,14 +14,18 @@ namespace mirx {
 
 namespace {
 
-constexpr int DT = 16;                 // output tile edge
-constexpr int DP = DT + 6;             // input patch edge (22)
 constexpr int DCH = 32;                // channels per workgroup
-constexpr int DPITCH = DP * DP + 1;    // 485
 
-__global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x, const float *__restrict__ w,
-                                                 const float *__restrict__ bias, int c, int h, int wd,
-                                                 float *__restrict__ y) {
+// DT = output tile edge, RPT = output rows per thread: 16 / 2 (256 threads, 22 x 22 patches, 62 KiB) for maps whose
+// side is a multiple of 16 (96, 48 in ConvNeXtV2-base @384), 12 / 3 (128 threads, 18 x 18 patches, 42 KiB) for the
+// 24- and 12-wide maps of stages 3 and 4, where a 16-wide tile would leave 44 % of its outputs outside the map.
+template <int DT, int RPT>
+__global__ __launch_bounds__(32 * (DT / RPT), 2) void k_dwconv7(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, int c, int h, int wd,
+                                                              float *__restrict__ y) {
+    constexpr int DP = DT + 6;             // input patch edge
+    constexpr int DPITCH = DP * DP + 1;    // odd: the 32 lanes of a half-wave (one per channel) never share a bank
+    constexpr int NTH = 32 * (DT / RPT);   // threads
     extern __shared__ __attribute__((aligned(16))) float sm[];     // [DCH][DPITCH]
     const int tiles_x = (wd + DT - 1) / DT;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
@@ -32,14 +36,14 @@ __global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x,
     // The global loads of a thread are issued in batches of 16 before the matching LDS stores (addresses clamped,
     // values zeroed when they are stored): with a load -> store loop the workgroup paid one HBM latency per element
     // (61 per thread); one batch of 61 costs more registers than two workgroups per CU can have.
-    constexpr int N_IN = (DCH * DP * DP + 255) / 256;           // 61 per thread
+    constexpr int N_IN = (DCH * DP * DP + NTH - 1) / NTH;       // 61 per thread (16 / 2), 81 (12 / 3)
     constexpr int NB = 16;
 #pragma unroll 1
     for (int t0 = 0; t0 < N_IN; t0 += NB) {
         float vin[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            int i = threadIdx.x + 256 * (t0 + t);
+            int i = threadIdx.x + NTH * (t0 + t);
             if (i >= DCH * DP * DP) i = DCH * DP * DP - 1;
             int ch = i / (DP * DP);
             const int r = (i / DP) % DP, q = i % DP;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x,
         }
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            const int i = threadIdx.x + 256 * (t0 + t);
+            const int i = threadIdx.x + NTH * (t0 + t);
             const int ch = i / (DP * DP), r = (i / DP) % DP, q = i % DP;
             const int yy = y0 + r - 3, xx = x0 + q - 3;
             const bool in = c0 + ch < c && yy >= 0 && yy < h && xx >= 0 && xx < wd;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x,
         }
     }
     __syncthreads();
-    const int ch = threadIdx.x & 31, rg = threadIdx.x >> 5;        // channel, pair of output rows
+    const int ch = threadIdx.x & 31, rg = threadIdx.x >> 5;        // channel, group of RPT output rows
     if (c0 + ch >= c) return;
     float wk[49];
 #pragma unroll
@@ -68,8 +72,8 @@ __global__ __launch_bounds__(256, 2) void k_dwconv7(const float *__restrict__ x,
     const float *pch = sm + ch * DPITCH;
     float *yo = y + img * (int64_t)h * wd * c + c0 + ch;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int r = rg * 2 + rr;
+    for (int rr = 0; rr < RPT; ++rr) {
+        const int r = rg * RPT + rr;
         if (y0 + r >= h) break;
         float acc[DT];
 #pragma unroll
@@ -141,11 +145,22 @@ __global__ __launch_bounds__(256) void k_grn_apply(float *__restrict__ x, int64_
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
                           float *y, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    const int tiles = ((h + DT - 1) / DT) * ((wd + DT - 1) / DT);
-    const size_t lds = (size_t)DCH * DPITCH * sizeof(float);
     if (n > 65535 || (c + DCH - 1) / DCH > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dwconv7, dim3((unsigned)tiles, (unsigned)((c + DCH - 1) / DCH), (unsigned)n), dim3(256), lds,
-                       st, x, w, bias, c, h, wd, y);
+    // tile edge: 12 when it wastes fewer outputs than 16 (24- and 12-wide maps), else 16
+    auto waste = [&](int dt) { return (int64_t)((h + dt - 1) / dt * dt) * ((wd + dt - 1) / dt * dt); };
+    if (waste(12) < waste(16)) {
+        constexpr int DT = 12, DP = DT + 6;
+        const int tiles = ((h + DT - 1) / DT) * ((wd + DT - 1) / DT);
+        const size_t lds = (size_t)DCH * (DP * DP + 1) * sizeof(float);
+        hipLaunchKernelGGL((k_dwconv7<12, 3>), dim3((unsigned)tiles, (unsigned)((c + DCH - 1) / DCH), (unsigned)n),
+                           dim3(128), lds, st, x, w, bias, c, h, wd, y);
+    } else {
+        constexpr int DT = 16, DP = DT + 6;
+        const int tiles = ((h + DT - 1) / DT) * ((wd + DT - 1) / DT);
+        const size_t lds = (size_t)DCH * (DP * DP + 1) * sizeof(float);
+        hipLaunchKernelGGL((k_dwconv7<16, 2>), dim3((unsigned)tiles, (unsigned)((c + DCH - 1) / DCH), (unsigned)n),
+                           dim3(256), lds, st, x, w, bias, c, h, wd, y);
+    }
     return hipGetLastError();
 }
 

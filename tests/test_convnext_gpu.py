@@ -14,7 +14,8 @@ def test_dwconv7_kernel():
     from mirx import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    for (b, c, h, w) in ((2, 128, 96, 96), (3, 40, 17, 23), (2, 1024, 12, 12), (1, 33, 5, 4)):
+    for (b, c, h, w) in ((2, 128, 96, 96), (3, 40, 17, 23), (2, 1024, 12, 12), (1, 33, 5, 4),
+                         (2, 64, 24, 24), (1, 32, 48, 20), (1, 96, 32, 16)):        # 12- and 16-wide tile variants
         x = torch.randn(b, c, h, w, generator=g)
         wt = 0.2 * torch.randn(c, 1, 7, 7, generator=g)
         bias = torch.randn(c, generator=g)
