@@ -55,6 +55,7 @@ SYMBOLS = {
     "mirx_topk_merge": (_int, [_vp, _vp, _int, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_rank_metrics": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _int, _int, ctypes.c_double, _int,
                                  ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp, _vp, _vp, _vp]),
+    "mirx_linear_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_linear_split3": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),

@@ -658,6 +658,20 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
     return MIRX_OK;
 }
 
+int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const float *bias_or_null, int n, int act,
+                        const float *residual_or_null, const float *gamma_or_null, float x_scale, float out_scale,
+                        float *y, void *stream) {
+    MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split2h: k must be a multiple of 16");
+    MIRX_CHECK(act == 0 || act == 1, "linear_split2h: act is 0 (none) or 1 (gelu)");
+    MIRX_CHECK(m == 0 || (x && w2 && y), "linear_split2h: null buffer");
+    MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split2h: gamma scales the residual branch only");
+    MIRX_CHECK(x != y, "linear_split2h: y may alias the residual, not the input");
+    MIRX_CHECK(x_scale > 0.f && out_scale > 0.f, "linear_split2h: scales must be positive powers of two");
+    MIRX_HIP(launch_linear_h2(x, m, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, act, residual_or_null,
+                              gamma_or_null, x_scale, out_scale, y, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w3,
                             const float *bias_or_null, int n, const float *residual_or_null,
                             const float *input_scale_or_null, float *y, void *stream) {

@@ -66,6 +66,10 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
                              const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
                              float *y, int64_t ybs, hipStream_t st);
 
+// ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
+hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
+                            const float *res, const float *gamma, float x_scale, float out_scale, float *y, hipStream_t st);
+
 // ---- k_linear_s3.hip ---------------------------------------------------------------------
 // tokens_per_image == 0: y / res are [m][n]; > 0: token t is pixel t % tpi of image t / tpi and y / res are NCHW
 hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,

@@ -27,6 +27,7 @@ MI355X path (CUDA tensors, eval mode):
 unless a local state dict is given via ``weights=``.
 """
 import ctypes
+import math
 from collections import OrderedDict
 
 import torch
@@ -352,6 +353,65 @@ def _accelerate_linears(root):
                 return _linear_s3(_m, x) if _linear_s3_ok(_m, x) else _orig(x)
             mod.forward = fwd
             mod._mirx_routed = True
+
+
+SPLIT2H_LINEAR = True    # Linears fed by a LayerNorm: two fp16 terms per operand (3 MFMAs per product) instead of three bf16
+
+
+def _linear_h2_weights(mod):
+    """(w2, w_scale): the two fp16 terms of W * w_scale, w_scale the power of two that puts the largest |w| in
+    [2^13, 2^14) (so the low term stays a normal fp16 number), laid out [ceil(n / 128)][k / 16][2][128][16]."""
+    w = mod.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cached = getattr(mod, "_mirx_w2", None)
+    if cached is None or cached[0] != key:
+        wf = w.detach().float()
+        amax = float(wf.abs().max())
+        ws = 2.0 ** math.floor(math.log2(16384.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        wf = wf * ws
+        if wf.shape[0] % 128:
+            wf = F.pad(wf, (0, 0, 0, 128 - wf.shape[0] % 128))
+        wh = wf.to(torch.float16)
+        wl = (wf - wh.float()).to(torch.float16)
+        n, k = wf.shape
+        t = torch.stack([wh, wl], 0).reshape(2, n // 128, 128, k // 16, 16)
+        cached = (key, t.permute(1, 3, 0, 2, 4).contiguous(), ws)
+        mod._mirx_w2 = cached
+    return cached[1], cached[2]
+
+
+def _layernorm_bound(ln):
+    """max |LayerNorm(x)_j| over all inputs: |x_j - mean| / std <= sqrt(C - 1), so sqrt(C - 1) max|gamma| + max|beta|."""
+    g, b = ln.weight, ln.bias
+    key = (None if g is None else g._version, None if b is None else b._version)
+    cached = getattr(ln, "_mirx_bound", None)
+    if cached is None or cached[0] != key:
+        c = ln.normalized_shape[-1]
+        gm = 1.0 if g is None else float(g.detach().abs().max())
+        bm = 0.0 if b is None else float(b.detach().abs().max())
+        cached = (key, math.sqrt(max(c - 1, 1)) * gm + bm)
+        ln._mirx_bound = cached
+    return cached[1]
+
+
+def _linear_h2_ok(mod, x, bound):
+    return (SPLIT2H_LINEAR and _linear_s3_ok(mod, x) and math.isfinite(bound) and 0.0 < bound < 3.0e4)
+
+
+def _linear_h2(mod, x, bound, act=0):
+    """[HIP] y = epi(x W^T + b) through mirx_linear_split2h; `bound` >= max |x| (the caller's proof obligation: fp16
+    terms overflow at 65504) -- x is scaled by the power of two that brings `bound` to at most 2^15."""
+    w2, ws = _linear_h2_weights(mod)
+    xs = 2.0 ** math.floor(math.log2(32768.0 / bound))
+    x = x.contiguous()
+    m = x.numel() // mod.in_features
+    out = torch.empty(x.shape[:-1] + (mod.out_features,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mirx_linear_split2h(_ptr(x), m, mod.in_features, _ptr(w2),
+                                                   _ptr(mod.bias.detach()) if mod.bias is not None else None,
+                                                   mod.out_features, act, None, None, xs, 1.0 / (xs * ws), _ptr(out),
+                                                   _stream(x.device)), "mirx_linear_split2h")
+    return out
 
 
 class _PackedQKV:
@@ -814,7 +874,10 @@ class _VitBlock(nn.Module):
             # epilogues) + the flash-attention kernel + 2 LayerNorms per block
             b, n, c = x.shape
             x = x.contiguous()
-            qkv = _linear_s3(at.qkv, self.norm1(x))
+            # the two Linears fed by a LayerNorm have a provable input bound: two fp16 terms (3 MFMAs per product)
+            b1, b2 = _layernorm_bound(self.norm1), _layernorm_bound(self.norm2)
+            h1 = self.norm1(x)
+            qkv = _linear_h2(at.qkv, h1, b1) if _linear_h2_ok(at.qkv, h1, b1) else _linear_s3(at.qkv, h1)
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 lib = _lib.load()
@@ -822,7 +885,9 @@ class _VitBlock(nn.Module):
                 _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
                            "mirx_attention_qkv_f32")
             x = _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma)
-            hid = _linear_s3(self.mlp.fc1, self.norm2(x), act=1)
+            h2 = self.norm2(x)
+            hid = (_linear_h2(self.mlp.fc1, h2, b2, act=1) if _linear_h2_ok(self.mlp.fc1, h2, b2)
+                   else _linear_s3(self.mlp.fc1, h2, act=1))
             return _linear_s3(self.mlp.fc2, hid, res=x, gamma=self.ls2.gamma, out=x)
         x = x + self.ls1(self.attn(self.norm1(x)))
         return x + self.ls2(self.mlp(self.norm2(x)))

@@ -156,3 +156,44 @@ def test_convnext_block_fused_matches_module_path():
             mm.SPLIT3_LINEAR = True
     assert got.shape == want.shape
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("m,k,n,act", [(300, 768, 2304, 0), (2745, 768, 3072, 1), (129, 1152, 4304, 0), (64, 48, 200, 1)])
+@pytest.mark.parametrize("xmax", [3.0, 900.0])
+def test_linear_split2h_matches_float64(m, k, n, act, xmax):
+    """mirx_linear_split2h (two fp16 terms per operand, caller-supplied power-of-two scales) against float64: the
+    tolerance of the bf16 three-term kernel.  Inputs bounded by `xmax` (what a LayerNorm bound provides)."""
+    import mirx.model as mm
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g).clamp(-4, 4) / 4.0 * xmax
+    x[0, 0] = xmax
+    x = x.to(dev)
+    lin = torch.nn.Linear(k, n).to(dev)
+    with torch.no_grad():
+        lin.weight.mul_(0.5)
+        lin.bias.normal_()
+    want = x.double() @ lin.weight.double().t() + lin.bias.double()
+    if act:
+        want = 0.5 * want * (1.0 + torch.erf(want / math.sqrt(2.0)))
+    with torch.no_grad():
+        got = mm._linear_h2(lin, x, xmax, act=act)
+    torch.cuda.synchronize()
+    err = float((got.double() - want).abs().max())
+    assert torch.isfinite(got).all()
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+
+
+def test_layernorm_bound_holds():
+    import mirx.model as mm
+    torch.manual_seed(0)
+    ln = torch.nn.LayerNorm(96)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.5)
+        ln.bias.normal_(0.0, 0.3)
+        x = torch.randn(4000, 96) * torch.logspace(-3, 3, 4000)[:, None]
+        x[0] = 0.0
+        x[0, 5] = 1e4                                               # one-hot row: the worst case of the bound
+        assert float(ln(x).abs().max()) <= mm._layernorm_bound(ln) * (1 + 1e-6)
