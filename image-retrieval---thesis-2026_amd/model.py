@@ -394,23 +394,48 @@ def _layernorm_bound(ln):
     return cached[1]
 
 
+def _linear_out_bound(ln, lin, rows=None):
+    """max |lin(LayerNorm(x))_j| over all inputs, for output rows `rows` (slice) of `lin`:
+    ||LN(x)||_2 <= max|gamma| sqrt(C) + ||beta||_2 (the normalised vector has squared norm C), so
+    |y_j| <= that * ||W_j||_2 + |b_j|.  GELU and softmax-weighted averages of such outputs obey the same bound."""
+    g, b = ln.weight, ln.bias
+    key = (None if g is None else g._version, None if b is None else b._version, lin.weight._version, lin.weight.data_ptr(),
+           None if lin.bias is None else lin.bias._version, None if rows is None else (rows.start, rows.stop))
+    store = lin.__dict__.setdefault("_mirx_out_bound", {})
+    if key not in store:
+        store.clear()
+        c = ln.normalized_shape[-1]
+        gm = 1.0 if g is None else float(g.detach().abs().max())
+        bn = 0.0 if b is None else float(torch.linalg.vector_norm(b.detach().double()))
+        w = lin.weight.detach() if rows is None else lin.weight.detach()[rows]
+        wn = float(torch.linalg.vector_norm(w.double(), dim=1).max())
+        bb = 0.0 if lin.bias is None else float((lin.bias.detach() if rows is None else lin.bias.detach()[rows]).abs().max())
+        store[key] = (gm * math.sqrt(c) + bn) * wn + bb
+    return store[key]
+
+
 def _linear_h2_ok(mod, x, bound):
     return (SPLIT2H_LINEAR and _linear_s3_ok(mod, x) and math.isfinite(bound) and 0.0 < bound < 3.0e4)
 
 
-def _linear_h2(mod, x, bound, act=0):
+def _linear_h2(mod, x, bound, act=0, res=None, gamma=None, out=None):
     """[HIP] y = epi(x W^T + b) through mirx_linear_split2h; `bound` >= max |x| (the caller's proof obligation: fp16
     terms overflow at 65504) -- x is scaled by the power of two that brings `bound` to at most 2^15."""
     w2, ws = _linear_h2_weights(mod)
     xs = 2.0 ** math.floor(math.log2(32768.0 / bound))
     x = x.contiguous()
     m = x.numel() // mod.in_features
-    out = torch.empty(x.shape[:-1] + (mod.out_features,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (mod.out_features,), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == out.shape
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().mirx_linear_split2h(_ptr(x), m, mod.in_features, _ptr(w2),
                                                    _ptr(mod.bias.detach()) if mod.bias is not None else None,
-                                                   mod.out_features, act, None, None, xs, 1.0 / (xs * ws), _ptr(out),
-                                                   _stream(x.device)), "mirx_linear_split2h")
+                                                   mod.out_features, act, _ptr(res) if res is not None else None,
+                                                   _ptr(gamma.detach()) if gamma is not None else None,
+                                                   xs, 1.0 / (xs * ws), _ptr(out), _stream(x.device)),
+                   "mirx_linear_split2h")
     return out
 
 
@@ -884,10 +909,16 @@ class _VitBlock(nn.Module):
                 att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
                 _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
                            "mirx_attention_qkv_f32")
-            x = _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma)
+            # attention output = softmax-weighted average of V rows: bounded like the V part of the qkv projection
+            ba = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
+            x = (_linear_h2(at.proj, a, ba, res=x, gamma=self.ls1.gamma) if _linear_h2_ok(at.proj, a, ba)
+                 else _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma))
             h2 = self.norm2(x)
             hid = (_linear_h2(self.mlp.fc1, h2, b2, act=1) if _linear_h2_ok(self.mlp.fc1, h2, b2)
                    else _linear_s3(self.mlp.fc1, h2, act=1))
+            bh = _linear_out_bound(self.norm2, self.mlp.fc1)                 # |gelu(v)| <= |v|
+            if _linear_h2_ok(self.mlp.fc2, hid, bh):
+                return _linear_h2(self.mlp.fc2, hid, bh, res=x, gamma=self.ls2.gamma, out=x)
             return _linear_s3(self.mlp.fc2, hid, res=x, gamma=self.ls2.gamma, out=x)
         x = x + self.ls1(self.attn(self.norm1(x)))
         return x + self.ls2(self.mlp(self.norm2(x)))

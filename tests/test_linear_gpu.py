@@ -197,3 +197,19 @@ def test_layernorm_bound_holds():
         x[0] = 0.0
         x[0, 5] = 1e4                                               # one-hot row: the worst case of the bound
         assert float(ln(x).abs().max()) <= mm._layernorm_bound(ln) * (1 + 1e-6)
+
+
+def test_linear_out_bound_holds():
+    import mirx.model as mm
+    torch.manual_seed(1)
+    ln = torch.nn.LayerNorm(64)
+    lin = torch.nn.Linear(64, 96)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.5)
+        ln.bias.normal_(0.0, 0.3)
+        lin.weight.normal_(0.0, 0.4)
+        x = torch.randn(5000, 64) * torch.logspace(-2, 3, 5000)[:, None]
+        y = lin(ln(x))
+        assert float(y.abs().max()) <= mm._linear_out_bound(ln, lin) * (1 + 1e-6)
+        assert float(y[:, 32:64].abs().max()) <= mm._linear_out_bound(ln, lin, slice(32, 64)) * (1 + 1e-6)
+        assert mm._linear_out_bound(ln, lin, slice(32, 64)) <= mm._linear_out_bound(ln, lin) + 1e-9
