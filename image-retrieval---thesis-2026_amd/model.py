@@ -350,7 +350,14 @@ def _accelerate_linears(root):
     for mod in root.modules():
         if type(mod) is nn.Linear and not getattr(mod, "_mirx_routed", False):
             def fwd(x, _m=mod, _orig=mod.forward):
-                return _linear_s3(_m, x) if _linear_s3_ok(_m, x) else _orig(x)
+                if not _linear_s3_ok(_m, x):
+                    return _orig(x)
+                bf = getattr(_m, "_mirx_in_bound", None)            # set where the input range is provable
+                if bf is not None:
+                    bound = bf()
+                    if _linear_h2_ok(_m, x, bound):
+                        return _linear_h2(_m, x, bound)
+                return _linear_s3(_m, x)
             mod.forward = fwd
             mod._mirx_routed = True
 
@@ -478,7 +485,9 @@ def _route_tower_attention(root):
                         and _m.head_dim in (32, 64, 72, 96) and _linear_s3_ok(_p, x) and x.shape[0] <= 65535):
                     _p._refresh()
                     b, n, c = x.shape
-                    qkv = _linear_s3(_p, x)
+                    bf = getattr(_m, "_mirx_in_bound", None)
+                    bound = bf() if bf is not None else float("inf")
+                    qkv = _linear_h2(_p, x, bound) if _linear_h2_ok(_p, x, bound) else _linear_s3(_p, x)
                     a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
                     with torch.cuda.device(x.device):
                         lib = _lib.load()
@@ -490,6 +499,25 @@ def _route_tower_attention(root):
 
             mod.forward = fwd
             mod._mirx_routed = True
+
+
+def _attach_tower_bounds(root):
+    """Input bounds for the Linears of transformers' SiglipEncoderLayer (pre-LN blocks): q / k / v and fc1 read a
+    LayerNorm output; out_proj reads softmax-weighted averages of V rows; fc2 reads gelu(fc1 output), |gelu(v)| <= |v|."""
+    for layer in root.modules():
+        if layer.__class__.__name__ != "SiglipEncoderLayer":
+            continue
+        try:
+            ln1, ln2, sa, mlp = layer.layer_norm1, layer.layer_norm2, layer.self_attn, layer.mlp
+            q, k, v, o, f1, f2 = sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj, mlp.fc1, mlp.fc2
+        except AttributeError:
+            continue
+        for lin in (q, k, v):
+            lin._mirx_in_bound = (lambda _ln=ln1: _layernorm_bound(_ln))
+        sa._mirx_in_bound = (lambda _ln=ln1: _layernorm_bound(_ln))
+        o._mirx_in_bound = (lambda _ln=ln1, _v=v: _linear_out_bound(_ln, _v))
+        f1._mirx_in_bound = (lambda _ln=ln2: _layernorm_bound(_ln))
+        f2._mirx_in_bound = (lambda _ln=ln2, _f=f1: _linear_out_bound(_ln, _f))
 
 
 def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
@@ -1090,6 +1118,7 @@ class MedSigLIP(nn.Module):
         self.projection = nn.Sequential(nn.Linear(hidden, 512), nn.LayerNorm(512), nn.ReLU(), nn.Linear(512, embed_dim))
         _accelerate_linears(self)                      # q/k/v/out projections, MLPs (4304 wide: padded tile), head
         _route_tower_attention(self.backbone)          # head_dim 72 flash attention on the packed projection
+        _attach_tower_bounds(self.backbone)            # provable input ranges -> two-fp16-term Linear kernel
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             for key in ("state-dict", "state_dict"):
