@@ -764,7 +764,10 @@ class _CnxBlock(nn.Module):
             # fc2 written back NCHW with the skip added in its epilogue
             lib = _lib.load()
             b, c, h, w = x.shape
-            hid = _linear_s3(mlp.fc1, self.norm(y), act=1)                 # [b, h, w, 4c]
+            yn = self.norm(y)
+            bn = _layernorm_bound(self.norm)                               # fc1 reads a LayerNorm output
+            hid = (_linear_h2(mlp.fc1, yn, bn, act=1) if _linear_h2_ok(mlp.fc1, yn, bn)
+                   else _linear_s3(mlp.fc1, yn, act=1))                    # [b, h, w, 4c]
             c4 = hid.shape[-1]
             gx = torch.empty((b, c4), dtype=torch.float32, device=x.device)
             out = torch.empty_like(xc)
