@@ -65,6 +65,7 @@ SYMBOLS = {
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_attention_qkv_f32": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),
+    "mirx_attention_qkv_f32_split2h": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_attention_qkv_f32_split3": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),

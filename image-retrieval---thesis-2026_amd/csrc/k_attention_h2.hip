@@ -1,0 +1,250 @@
+// k_attention_h2.hip -- k_attention_s3 (flash attention, fp32 in / fp32 out, head_dim 64) with every operand carried as
+// TWO fp16 terms and THREE v_mfma_f32_32x32x16_f16 per product block instead of three bf16 terms and six MFMAs (see
+// k_linear_h2.hip for the arithmetic and the measured error).  fp16's range is the caller's contract: `qk_bound` >=
+// max |q|, |k| and `v_bound` >= max |v| over the packed projection (mirx.model derives them from the LayerNorm and
+// the projection's row norms); the launcher turns them into exact power-of-two scales: Q is staged as
+// q * (scale log2 e) * qs, K as k * ks, V as v * vs, the probabilities (in [0, 1]) as p * 1024, and the
+// accumulators are multiplied back by 1 / (qs ks) before the softmax and 1 / (1024 vs) at the end.
+// Layout, key permutation and LDS swizzles are k_attention_s3's; an LDS buffer is 16 KiB instead of 24.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;   // (fp16 here)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
+
+constexpr int DH = 64;                 // head dimension
+constexpr int KT = 32;                 // keys per tile
+constexpr int K_PLANE = KT * DH * 2;   // bytes of one term of the K tile (4 KiB)
+constexpr int V_PLANE = DH * KT * 2;   // bytes of one term of the V^T tile (4 KiB)
+constexpr int BUF = 2 * K_PLANE + 2 * V_PLANE;   // 16 KiB
+
+__device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
+    const f32x2 v = {a, b};
+    const bf16x2 vh = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(vh, f32x2);
+    const bf16x2 vl = __builtin_convertvector(r1, bf16x2);
+    h = __builtin_bit_cast(unsigned, vh);
+    l = __builtin_bit_cast(unsigned, vl);
+}
+
+// 8 fp32 values -> two fp16x8 fragments
+__device__ inline void split8(const float (&v)[8], bf16x8 &h, bf16x8 &l) {
+    u32x4 ph, pl;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned th, tl;
+        split2(v[2 * p], v[2 * p + 1], th, tl);
+        ph[p] = th; pl[p] = tl;
+    }
+    h = __builtin_bit_cast(bf16x8, ph);
+    l = __builtin_bit_cast(bf16x8, pl);
+}
+
+#define MIRX_MFMA3(C, AH, AL, BH, BL)                                               \
+    {                                                                               \
+        C = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, C, 0, 0, 0);             \
+        C = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, C, 0, 0, 0);             \
+        C = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, C, 0, 0, 0);             \
+    }
+
+__global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict__ qkv, int n, int heads,
+                                                         float q_mul, float k_mul, float v_mul, float s_inv, float o_inv,
+                                                         float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char sm[2 * BUF];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, nq = lane & 31;
+    const int head = blockIdx.y;
+    const int64_t img = blockIdx.z;
+    const int64_t tok = 3 * (int64_t)heads * DH;                          // floats per token in qkv
+    const float *base = qkv + img * n * tok + head * DH;                   // q of token t: base + t*tok; k: + heads*DH; v: + 2*heads*DH
+    const int q_idx = blockIdx.x * 128 + wave * 32 + nq;
+    const int q_ld = q_idx < n ? q_idx : n - 1;
+
+    // this lane's query: channels 16 ks + 8 half + i, pre-multiplied by scale * log2(e), three terms each
+    bf16x8 qh[4], ql[4];
+    {
+        const float *qp = base + q_ld * tok + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(qp + 16 * ks), b = *reinterpret_cast<const f32x4 *>(qp + 16 * ks + 4);
+            const float v[8] = {a[0] * q_mul, a[1] * q_mul, a[2] * q_mul, a[3] * q_mul,
+                                b[0] * q_mul, b[1] * q_mul, b[2] * q_mul, b[3] * q_mul};
+            split8(v, qh[ks], ql[ks]);
+        }
+    }
+
+    // ---- staging assignments ------------------------------------------------------------------------------------
+    // K: thread -> key t >> 3, channels 8 (t & 7) .. + 7 (two float4)        -> one 16-byte chunk per term
+    // V: thread -> keys 2 (t >> 4), 2 (t >> 4) + 1, channels 4 (t & 15) .. + 3  -> four bf16 pairs per term
+    const int kk = threadIdx.x >> 3, kc = threadIdx.x & 7;
+    const int k_lds = kk * 128 + ((kc ^ ((kk >> 1) & 7)) << 4);                   // + term * K_PLANE
+    const int vm_ = threadIdx.x >> 4, vc = threadIdx.x & 15;
+    const int vkey = 2 * vm_;
+    // position of key k on the permuted axis: 16 (k >> 4) + 8 ((k >> 2) & 1) + (k & 3) + 4 ((k >> 3) & 1)
+    const int vpos = 16 * (vkey >> 4) + 8 * ((vkey >> 2) & 1) + (vkey & 3) + 4 * ((vkey >> 3) & 1);   // even
+    int v_lds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = 4 * vc + j;
+        v_lds[j] = 2 * K_PLANE + d * 64 + ((((vpos >> 3) ^ ((d >> 2) & 3))) << 4) + (vpos & 7) * 2;   // + term * V_PLANE
+    }
+    f32x4 rk[2], rv[2];
+    auto load_tile = [&](int kt) {
+        int key = kt * KT + kk;
+        if (key >= n) key = n - 1;                                        // masked later
+        const float *kp = base + key * tok + heads * DH + 8 * kc;
+        rk[0] = *reinterpret_cast<const f32x4 *>(kp);
+        rk[1] = *reinterpret_cast<const f32x4 *>(kp + 4);
+        int k0 = kt * KT + vkey, k1 = k0 + 1;
+        if (k0 >= n) k0 = n - 1;
+        if (k1 >= n) k1 = n - 1;                                          // P is 0 there
+        rv[0] = *reinterpret_cast<const f32x4 *>(base + k0 * tok + 2 * heads * DH + 4 * vc);
+        rv[1] = *reinterpret_cast<const f32x4 *>(base + k1 * tok + 2 * heads * DH + 4 * vc);
+    };
+    auto store_tile = [&](int buf) {
+        char *sb = sm + buf * BUF;
+        u32x4 ph, pl;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned th, tl;
+            split2(rk[p >> 1][2 * (p & 1)] * k_mul, rk[p >> 1][2 * (p & 1) + 1] * k_mul, th, tl);
+            ph[p] = th; pl[p] = tl;
+        }
+        *reinterpret_cast<u32x4 *>(sb + k_lds) = ph;
+        *reinterpret_cast<u32x4 *>(sb + k_lds + K_PLANE) = pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned th, tl;
+            split2(rv[0][j] * v_mul, rv[1][j] * v_mul, th, tl);            // keys 2m, 2m + 1 of channel 4 vc + j
+            *reinterpret_cast<unsigned *>(sb + v_lds[j]) = th;
+            *reinterpret_cast<unsigned *>(sb + v_lds[j] + V_PLANE) = tl;
+        }
+    };
+
+    // fragment addresses: K row nq (key), chunk 2 ks + half; V^T row 32 t + nq (d), chunk 2 s + half
+    int fk[4], fv[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fk[ks] = nq * 128 + (((2 * ks + half) ^ ((nq >> 1) & 7)) << 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int d = 32 * t + nq;
+            fv[t][s] = 2 * K_PLANE + d * 64 + (((2 * s + half) ^ ((d >> 2) & 3)) << 4);
+        }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = (n + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();                                   // tile kt visible; buffer cur ^ 1 free
+        load_tile(kt + 1 < ntiles ? kt + 1 : kt);          // branch-free: the last tile re-loads itself
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = sm + cur * BUF;
+
+        // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fk[ks]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + K_PLANE);
+            MIRX_MFMA3(sacc, ah, al, qh[ks], ql[ks])
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= s_inv;      // exact: a power of two
+
+        // ---- online softmax over this lane's 16 keys (base 2) -----------------------------------------------------
+        const int key0 = kt * KT + 4 * half;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + (r & 3);
+            if (key >= n) sacc[r] = -INFINITY;
+            mt = fmaxf(mt, sacc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));            // the other 16 keys of the same query
+        const float m_new = fmaxf(m_run, mt);              // finite: every tile holds at least one valid key
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = exp2f(sacc[r] - m_new);
+            psum += sacc[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+        // ---- O^T += V^T P^T: step s contracts the keys kappa(8 s + i, half) = this lane's sacc[8 s + i] -------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float pv[8] = {sacc[8 * s] * 1024.f, sacc[8 * s + 1] * 1024.f, sacc[8 * s + 2] * 1024.f, sacc[8 * s + 3] * 1024.f,
+                                 sacc[8 * s + 4] * 1024.f, sacc[8 * s + 5] * 1024.f, sacc[8 * s + 6] * 1024.f, sacc[8 * s + 7] * 1024.f};
+            bf16x8 bh, bl;
+            split8(pv, bh, bl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s] + V_PLANE);
+                MIRX_MFMA3(o[t], ah, al, bh, bl)
+            }
+        }
+        store_tile(cur ^ 1);
+    }
+
+    // ---- normalise and store: register r of o[t] is channel 32 t + 8 (r >> 2) + (r & 3) + 4 half ------------------
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q_idx < n) {
+        const float inv = o_inv / l_run;
+        float *op = out + ((img * n + q_idx) * heads + head) * DH + 4 * half;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
+                *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale,
+                               float qk_bound, float v_bound, float *out, hipStream_t st) {
+    if (batch <= 0 || n <= 0) return hipSuccess;
+    if (head_dim != DH || heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (!(qk_bound > 0.f) || !(v_bound > 0.f) || !(scale > 0.f)) return hipErrorInvalidValue;
+    const float sl = scale * 1.4426950408889634f;
+    // powers of two that bring each operand's bound to at most 2^14 (fp16 max 65504)
+    const float qs = exp2f(floorf(log2f(16384.0f / (qk_bound * sl))));
+    const float ks = exp2f(floorf(log2f(16384.0f / qk_bound)));
+    const float vs = exp2f(floorf(log2f(16384.0f / v_bound)));
+    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(k_attention_h2, grid, dim3(256), 0, st, qkv, n, heads, sl * qs, ks, vs, 1.0f / (qs * ks),
+                       1.0f / (1024.0f * vs), out);
+    return hipGetLastError();
+}
+
+}  // namespace mirx

@@ -92,6 +92,9 @@ hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, i
 // ---- k_attention_s3.hip: the same attention on three-term bf16 MFMAs (head_dim 64) ------------------
 hipError_t launch_attention_s3(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                                hipStream_t st);
+// ---- k_attention_h2.hip: the same attention on two fp16 terms per operand (head_dim 64, caller-supplied bounds) --
+hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale,
+                               float qk_bound, float v_bound, float *out, hipStream_t st);
 
 // ---- k_metrics.hip ----------------------------------------------------------------------
 constexpr int MIRX_MAX_KAPPAS = 8;

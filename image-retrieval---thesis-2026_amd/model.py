@@ -937,9 +937,16 @@ class _VitBlock(nn.Module):
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 lib = _lib.load()
-                att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
-                _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
-                           "mirx_attention_qkv_f32")
+                bqk = _linear_out_bound(self.norm1, at.qkv, slice(0, 2 * c))
+                bv = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
+                if SPLIT2H_LINEAR and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+                    # q, k, v are outputs of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
+                    _lib.check(lib.mirx_attention_qkv_f32_split2h(_ptr(qkv), b, n, at.num_heads, 64, 0.125, bqk, bv, _ptr(a),
+                                                                  _stream(x.device)), "mirx_attention_qkv_f32_split2h")
+                else:
+                    att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                    _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
+                               "mirx_attention_qkv_f32")
             # attention output = softmax-weighted average of V rows: bounded like the V part of the qkv projection
             ba = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
             x = (_linear_h2(at.proj, a, ba, res=x, gamma=self.ls1.gamma) if _linear_h2_ok(at.proj, a, ba)

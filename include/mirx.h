@@ -270,6 +270,15 @@ int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens,
                                   float scale, float *out, void *stream);
 
 /*
+ * mirx_attention_qkv_f32 with both GEMMs on TWO fp16 terms per operand (three MFMAs per product block; see
+ * mirx_linear_split2h).  qk_bound >= max |q|, |k| and v_bound >= max |v| over the packed projection are the caller's
+ * contract (fp16 range; mirx.model derives them from the LayerNorm in front of the projection and its row norms);
+ * the library turns them into exact power-of-two scales.  head_dim must be 64.
+ */
+int mirx_attention_qkv_f32_split2h(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
+                                   float scale, float qk_bound, float v_bound, float *out, void *stream);
+
+/*
  * Metric tail over ranked lists, on the device: one pass per query over its
  * ranking `ranks[q, 0..n)` (gallery row ids, best first; rows `row_stride` apart) gives
  *   out_ap[q]      AP of the list: ap_kind 0 = the trapezoidal compute_ap of test.py:58-92 summed the
