@@ -61,6 +61,11 @@ SYMBOLS = {
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
+    "mirx_conv1x1_bn_relu_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64,
+                                            _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "mirx_stem_conv7_bn_relu_pool_split3_into": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp]),
+    "mirx_conv3x3_winograd_nchw_ranged": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp]),
+    "mirx_conv3x3_direct_split2h_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),

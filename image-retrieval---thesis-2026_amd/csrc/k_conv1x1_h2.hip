@@ -1,0 +1,243 @@
+// k_conv1x1_h2.hip -- the dense-layer 1x1 convolution of k_conv1x1_s3.hip with every fp32 operand carried as TWO fp16
+// terms (x = xh + xl to 22 bits) and THREE v_mfma_f32_32x32x16_f16 per product block (xl wh + xh wl + xh wh; the
+// dropped xl wl is 2^-22 of the product) instead of three bf16 terms and six MFMAs -- the scheme of k_linear_h2.hip.
+// Half the matrix-pipe time and 4 instead of 6 LDS bytes per element; the layer then runs against its HBM stream.
+//
+// fp16 has 5 exponent bits, so the kernel needs the RANGE of its input.  DenseNet activations have no a-priori bound,
+// so the range travels with the data: every kernel that writes into a dense block's buffer also publishes the largest
+// |value| it wrote (`amax` slots: 64 floats, slot = workgroup % 64, combined with an unsigned atomic max -- the bit
+// patterns of non-negative floats order like the floats).  This kernel reads the 64 slots of its input buffer, and
+//     bound = in_ks * max(slots) + in_kb      (in_ks = max |BN scale|, in_kb = max |BN shift| of the prologue; 1, 0 without)
+// is an upper bound of every value it stages; x_scale = the power of two with bound * x_scale in [2^14, 2^15).  A value
+// below 2^-18 of the bound keeps an ABSOLUTE error of 2^-40 of the bound (fp16 subnormal low term), everything else 22
+// bits.  The weights arrive pre-split with one power-of-two scale PER OUTPUT CHANNEL (largest |w| of the row in
+// [2^13, 2^14)); `oscale[o]` = 1 / that scale is applied to the accumulator together with 1 / x_scale -- all exact.
+// The epilogue publishes the largest |output| in `out_amax` the same way.
+//
+// Contract otherwise as mirx_conv1x1_bn_relu_split3: y = act_out(W * act_in(x) + bias), NCHW, tile 128 output
+// channels x 128 pixels, 16-channel stages, double-buffered LDS (32 KiB), weights by LDS DMA, activations
+// register-prefetched.  w2 = [cout / 128][cin / 16][2 terms][128 out][16 in] fp16.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+constexpr int CM = 128;            // output channels per workgroup
+constexpr int CP = 128;            // pixels per workgroup
+constexpr int KC = 16;             // channels per stage
+constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage (4 KiB)
+constexpr int PLANE_B = CP * KC * 2;
+constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // 16 KiB
+
+template <bool PROLOGUE, bool RELU_OUT>
+__global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift,
+                                                       const uint16_t *__restrict__ w2,
+                                                       const float *__restrict__ oscale,
+                                                       const float *__restrict__ bias, int64_t n, int hw, int cout,
+                                                       float *__restrict__ y, int64_t ybs,
+                                                       const float *__restrict__ in_amax, float in_ks, float in_kb,
+                                                       unsigned *__restrict__ out_amax) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    __shared__ float sBias[CM], sOsc[CM];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t total = n * (int64_t)hw;
+    const int64_t p0 = (int64_t)blockIdx.x * CP;
+    const int co0 = blockIdx.y * CM;
+    const int nk = cin / KC;
+
+    // ---- the input range -> x_scale (a power of two), identical in every lane --------------------------------
+    float x_scale, x_inv;
+    range_scales(fmaf(in_ks, in_amax ? range_read(in_amax) : 0.f, in_kb), x_scale, x_inv);
+
+    // ---- staging assignments ------------------------------------------------------------------------
+    // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
+    const int b_px = threadIdx.x & 127;
+    const int b_kg = wave >> 1;
+    int64_t b_off = 0;
+    {
+        const int64_t pp = p0 + b_px;
+        if (pp < total) b_off = (pp / hw) * xbs + (pp % hw);
+    }
+    const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * hw;
+    const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + term * PLANE_B
+    // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
+    // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
+    // l / 2, slot l & 1), which holds source chunk (l & 1) ^ ((row >> 3) & 1) -- the same for every piece.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)), 0, nk * (2 * CM * KC * 2), 0x00020000);
+    const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    auto dma_w = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE + piece * 1024), 16, w_voff,
+                                                     kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
+        }
+    };
+
+    // TWO register sets: the activation loads of stage kt + 2 are issued while stage kt computes and stage kt + 1
+    // waits in the other set.  With one set a workgroup has 8 KiB of HBM reads in flight (32 KiB per CU at four
+    // workgroups): by Little's law that caps the layer near 4 TB/s, which is where the one-set kernel sat.
+    float ra[8], rb[8], sca[8], sha[8], scb[8], shb[8];
+    auto load = [&](int kt, float (&r)[8], float (&rsc)[8], float (&rsh)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = xsrc[((int64_t)kt * KC + j) * hw];
+        if (PROLOGUE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rsc[j] = scale[kt * KC + 8 * b_kg + j];
+                rsh[j] = shift[kt * KC + 8 * b_kg + j];
+            }
+        }
+    };
+    auto store = [&](int buf, const float (&r)[8], const float (&rsc)[8], const float (&rsh)[8]) {
+        char *sb = sm + buf * STAGE;
+        // two fp16 terms of each (scaled) value, two values at a time (round to nearest even)
+        u32x4 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 v = {r[2 * j], r[2 * j + 1]};
+            if (PROLOGUE) {
+                v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
+                v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
+            }
+            v = v * x_scale;
+            const f16x2 h = __builtin_convertvector(v, f16x2);
+            const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+            const f16x2 l = __builtin_convertvector(r1, f16x2);
+            ph[j] = __builtin_bit_cast(unsigned, h);
+            pl[j] = __builtin_bit_cast(unsigned, l);
+        }
+        *reinterpret_cast<u32x4 *>(sb + b_lds) = ph;
+        *reinterpret_cast<u32x4 *>(sb + b_lds + PLANE_B) = pl;
+    };
+
+    // ---- fragment addressing: lane -> row (lane & 31), K chunk (lane >> 5) -------------------------------
+    const int kg = lane >> 5;
+    int fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra_ = wm * 64 + t * 32 + (lane & 31);
+        fa[t] = ra_ * 32 + ((kg ^ ((ra_ >> 3) & 1)) << 4);
+        const int rb_ = wn * 64 + t * 32 + (lane & 31);
+        fb[t] = 2 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (threadIdx.x < CM) {
+        sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+        sOsc[threadIdx.x] = oscale[co0 + threadIdx.x] * x_inv;
+    }
+    // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
+    auto stage = [&](int kt, int cur, float (&rnext)[8], float (&scn)[8], float (&shn)[8], const float (&rstore)[8],
+                     const float (&scs)[8], const float (&shs)[8]) {
+        // stage kt visible: this wave's weight DMA of stage kt has landed (the two DMA pieces are OLDER than the 8
+        // activation loads of stage kt + 1 issued behind them, which stay in flight: vmcnt(8)); buffer cur ^ 1 free
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
+        load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = sm + cur * STAGE;
+        f16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                a[t][p] = *reinterpret_cast<const f16x8 *>(sb + fa[t] + p * PLANE_A);
+                b[t][p] = *reinterpret_cast<const f16x8 *>(sb + fb[t] + p * PLANE_B);
+            }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                f32x16 c = acc[mi][ni];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
+    };
+    dma_w(0, 0);
+    load(0, ra, sca, sha);
+    load(nk > 1 ? 1 : 0, rb, scb, shb);
+    store(0, ra, sca, sha);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        stage(kt, 0, ra, sca, sha, rb, scb, shb);
+        stage(kt + 1, 1, rb, scb, shb, ra, sca, sha);
+    }
+    if (kt < nk) stage(kt, 0, ra, sca, sha, rb, scb, shb);
+
+    // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
+    // pixel p0 + 64 wn + 32 ni + (lane & 31)
+    float vmax = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
+        if (pp >= total) continue;
+        const int64_t bimg = pp / hw, off = pp % hw;
+        float *yo = y + bimg * ybs + off;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = fmaf(acc[mi][ni][r], sOsc[ch - co0], sBias[ch - co0]);
+                if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
+                vmax = range_max(vmax, v);
+                yo[(int64_t)ch * hw] = v;
+            }
+    }
+    if (out_amax) range_publish(out_amax, vmax, lane);
+}
+
+}  // namespace
+
+hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                             const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
+                             int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
+                             float *out_amax, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (cin % KC || cout % CM || !oscale) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
+    const size_t lds = 2 * (size_t)STAGE;
+    unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
+#define MIRX_H2C(P, R)                                                                                     \
+    {                                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa);                                \
+    }
+    if (scale) {
+        if (relu_out) MIRX_H2C(true, true) else MIRX_H2C(true, false)
+    } else {
+        if (relu_out) MIRX_H2C(false, true) else MIRX_H2C(false, false)
+    }
+#undef MIRX_H2C
+    return hipGetLastError();
+}
+
+}  // namespace mirx

@@ -35,7 +35,8 @@ constexpr int U_STAGE = 16 * KC * COUT;       // floats of transformed weights p
 // a 14-wide map holds three tile rows
 template <int W, int R>
 __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict__ x, const float *__restrict__ u,
-                                                      float *__restrict__ out, int64_t out_bs) {
+                                                      float *__restrict__ out, int64_t out_bs,
+                                                      unsigned *__restrict__ out_range) {
     constexpr int TW = W / 2;                 // tiles per row
     constexpr int ROWS = 2 * R + 2;           // input rows of a strip
     constexpr int PITCH = W + 4;              // input row pitch in LDS: col -1 at index 1, even, >= W + 3
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict
     }
     __syncthreads();
     // item = (oc, tile): 32 x 28 items, 256 threads; lanes walk tiles -> coalesced float2 stores
+    float vmax = 0.f;                                       // largest |output| (range slots, mirx_common.h)
     float *oi = out + img * out_bs;
     for (int it = threadIdx.x; it < COUT * 32; it += 256) {
         const int oc = it >> 5, t = it & 31;
@@ -189,10 +191,14 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict
                 p[i][1] = s_x[i * XB + COUT * 32 + oc * 32 + t];
             }
             float *o = oi + ((int64_t)oc * W + oy0 + 2 * otr) * W + 2 * otc;
-            *reinterpret_cast<float2 *>(o) = make_float2(p[0][0] + p[1][0] + p[2][0], p[0][1] + p[1][1] + p[2][1]);
-            *reinterpret_cast<float2 *>(o + W) = make_float2(p[1][0] - p[2][0] - p[3][0], p[1][1] - p[2][1] - p[3][1]);
+            const float2 v0 = make_float2(p[0][0] + p[1][0] + p[2][0], p[0][1] + p[1][1] + p[2][1]);
+            const float2 v1 = make_float2(p[1][0] - p[2][0] - p[3][0], p[1][1] - p[2][1] - p[3][1]);
+            *reinterpret_cast<float2 *>(o) = v0;
+            *reinterpret_cast<float2 *>(o + W) = v1;
+            vmax = range_max(range_max(range_max(range_max(vmax, v0.x), v0.y), v1.x), v1.y);
         }
     }
+    if (out_range) range_publish(out_range, vmax, threadIdx.x & 63);
 }
 
 // The 7x7 maps (last dense block): a map is 4 x 4 tiles (the 8th row / column of outputs is computed and
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict
 // layout as k_conv3x3_wino; the input is staged cell by cell (rows of 7 floats have no vector alignment)
 // into zero-initialised 10 x 12 planes whose border cells are never written.
 __global__ __launch_bounds__(256, 3) void k_conv3x3_wino7(const float *__restrict__ x, const float *__restrict__ u,
-                                                          float *__restrict__ out, int64_t out_bs, int64_t n_img) {
+                                                          float *__restrict__ out, int64_t out_bs, int64_t n_img,
+                                                          unsigned *__restrict__ out_range) {
     constexpr int W = 7, ROWS = 10, PITCH = 12;
     constexpr int PLANE = ROWS * PITCH;                  // one channel of one image
     constexpr int IN_STAGE = 2 * KC * PLANE;
@@ -296,6 +303,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino7(const float *__restric
         s_x[wave * XB + COUT * 32 + oc * 32 + n] = acc[1][r] - acc[2][r] - acc[3][r];
     }
     __syncthreads();
+    float vmax = 0.f;
     for (int it = threadIdx.x; it < COUT * 32; it += 256) {
         const int oc = it >> 5, t = it & 31;
         const int oim = t >> 4, otr = (t & 15) >> 2, otc = t & 3;
@@ -308,17 +316,23 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino7(const float *__restric
         }
         float *o = out + (img0 + oim) * out_bs + ((int64_t)oc * W + 2 * otr) * W + 2 * otc;
         const bool col1 = 2 * otc + 1 < W, row1 = 2 * otr + 1 < W;
-        o[0] = p[0][0] + p[1][0] + p[2][0];
-        if (col1) o[1] = p[0][1] + p[1][1] + p[2][1];
+        const float v00 = p[0][0] + p[1][0] + p[2][0], v01 = p[0][1] + p[1][1] + p[2][1];
+        const float v10 = p[1][0] - p[2][0] - p[3][0], v11 = p[1][1] - p[2][1] - p[3][1];
+        o[0] = v00;
+        vmax = range_max(vmax, v00);
+        if (col1) { o[1] = v01; vmax = range_max(vmax, v01); }
         if (row1) {
-            o[W] = p[1][0] - p[2][0] - p[3][0];
-            if (col1) o[W + 1] = p[1][1] - p[2][1] - p[3][1];
+            o[W] = v10;
+            vmax = range_max(vmax, v10);
+            if (col1) { o[W + 1] = v11; vmax = range_max(vmax, v11); }
         }
     }
+    if (out_range) range_publish(out_range, vmax, lane);
 }
 
 template <int W, int R>
-hipError_t launch_w(const float *x, const float *u, int64_t n, float *out, int64_t out_bs, hipStream_t st) {
+hipError_t launch_w(const float *x, const float *u, int64_t n, float *out, int64_t out_bs, unsigned *out_range,
+                    hipStream_t st) {
     constexpr int ROWS = 2 * R + 2, PITCH = W + 4;
     const size_t stage = (size_t)(2 * U_STAGE + 2 * KC * ROWS * PITCH) * sizeof(float);
     const size_t xch = (size_t)4 * 2 * COUT * 32 * sizeof(float);
@@ -327,25 +341,26 @@ hipError_t launch_w(const float *x, const float *u, int64_t n, float *out, int64
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_conv3x3_wino<W, R>), dim3((W / 2 + R - 1) / R, (unsigned)n), dim3(256), lds, st, x, u, out,
-                       out_bs);
+                       out_bs, out_range);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
-                               hipStream_t st) {
+                               float *out_range_f, hipStream_t st) {
+    unsigned *out_range = reinterpret_cast<unsigned *>(out_range_f);
     if (n <= 0) return hipSuccess;
     if (n > 65535) return hipErrorInvalidValue;
-    if (side == 56) return launch_w<56, 1>(x, u, n, out, out_bs, st);
-    if (side == 28) return launch_w<28, 2>(x, u, n, out, out_bs, st);
-    if (side == 14) return launch_w<14, 4>(x, u, n, out, out_bs, st);
+    if (side == 56) return launch_w<56, 1>(x, u, n, out, out_bs, out_range, st);
+    if (side == 28) return launch_w<28, 2>(x, u, n, out, out_bs, out_range, st);
+    if (side == 14) return launch_w<14, 4>(x, u, n, out, out_bs, out_range, st);
     if (side == 7) {
         const size_t lds = (size_t)(2 * U_STAGE + 2 * 2 * KC * 10 * 12) * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_wino7),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_conv3x3_wino7, dim3((unsigned)((n + 1) / 2)), dim3(256), lds, st, x, u, out, out_bs, n);
+        hipLaunchKernelGGL(k_conv3x3_wino7, dim3((unsigned)((n + 1) / 2)), dim3(256), lds, st, x, u, out, out_bs, n, out_range);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;

@@ -1,0 +1,257 @@
+// k_conv3x3_d2h.hip -- the direct implicit-GEMM 3x3 convolution of k_conv3x3_d3.hip (DenseNet dense layer, 128 -> 32
+// channels, stride 1, pad 1, no bias) with every fp32 operand carried as TWO fp16 terms (x = xh + xl to 22 bits) and
+// THREE v_mfma_f32_32x32x16_f16 per product block (wl xh + wh xl + wh xh; the dropped wl xl is 2^-22 of the
+// product) instead of three bf16 terms and six MFMAs: half the matrix time, 4 instead of 6 LDS bytes per element, 72
+// instead of 108 weight-fragment registers.
+//
+//   D[oc, pixel] += W[oc, (tap, c)] * X[(tap, c), pixel]     K = 9 taps x 128 channels, one MFMA step = one tap x 16 c
+//
+// fp16 has 5 exponent bits, so the input's range travels with it (mirx_common.h, "value ranges"): the producing 1x1
+// conv publishes the largest value of the bottleneck map in 64 range slots; this kernel stages x * 2^s with
+// max * 2^s in [2^14, 2^15), reads weights that were scaled per OUTPUT channel by the caller (largest |w| of the
+// channel in [2^13, 2^14): mirx.model._conv3x3_weights_split2h) and multiplies the accumulator by oscale[oc] / 2^s.
+// It publishes the largest |output| it wrote into the destination buffer's range slots.
+//
+// Geometry, staging and the weight-fragment schedule are k_conv3x3_d3's:
+// one workgroup (4 waves) = a strip of R rows x W columns = 224 (196 for the 14 x 14 map) output pixels of one image
+// = 7 column blocks of 32 pixels (waves 0..2 take two, wave 3 one) x all 32 output channels.
+//   * X: 16-channel stages; the padded strip ((R + 2) x (W + 2) pixels) is split into its two fp16 terms while it
+//     is staged and stored pixel-major -- [term][padded pixel][16 channels] fp16, the two 16-byte halves of a pixel
+//     at slot h ^ ((pixel >> 3) & 1) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
+//     ds_read_b128 per term.  Double-buffered, register-prefetched.
+//   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][2 terms][32 oc][16 c] fp16); a lane reads its
+//     16-byte A fragments straight from global memory (147 KiB per layer, L2-resident): taps 0..3 at the end of the
+//     previous stage, taps 4..8 two taps ahead of their use.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+constexpr int CIN = 128, COUT = 32;
+constexpr int KC = 16;                        // channels per stage = one MFMA K
+constexpr int NST = CIN / KC;                 // 8 stages
+
+__device__ inline void split2h(float a, float b, unsigned &h, unsigned &l) {
+    const f32x2 v = {a, b};
+    const f16x2 vh = __builtin_convertvector(v, f16x2);
+    const f32x2 r1 = v - __builtin_convertvector(vh, f32x2);
+    const f16x2 vl = __builtin_convertvector(r1, f16x2);
+    h = __builtin_bit_cast(unsigned, vh);
+    l = __builtin_bit_cast(unsigned, vl);
+}
+
+// W = map side (56 / 28 / 14); R = output rows per strip (4 / 8 / 14)
+template <int W, int R>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict__ x, const uint16_t *__restrict__ w3,
+                                                        const float *__restrict__ oscale, float *__restrict__ out,
+                                                        int64_t out_bs, const float *__restrict__ in_range,
+                                                        unsigned *__restrict__ out_range) {
+    constexpr int PW = W + 2, PR = R + 2;     // padded strip
+    constexpr int NPIX = PR * PW;             // padded pixels of a stage
+    constexpr int PLANE = NPIX * 32;          // bytes of one term of one stage (32 B per pixel)
+    constexpr int STAGE = 2 * PLANE;
+    constexpr int NOUT = R * W;               // output pixels of a full strip
+    constexpr int NBLK = (NOUT + 31) / 32;    // 7
+    static_assert(NBLK <= 8, "two column blocks per wave");
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = lane >> 5, n = lane & 31;
+    const int strip = blockIdx.x;
+    const int64_t img = blockIdx.y;
+    const int oy0 = strip * R;                                // first output row of the strip
+    const float *xi = x + img * CIN * (int64_t)(W * W);
+    float x_scale, x_inv;
+    range_scales(range_read(in_range), x_scale, x_inv);
+
+    // ---- staging: item = (padded pixel, 8-channel half); thread t takes items t, t + 256, ... ----------------------
+    constexpr int NITEM = 2 * NPIX;
+    constexpr int IPT = (NITEM + 255) / 256;                  // items per thread (3 for 56 / 28, 2 for 14)
+    float rin[IPT][8];
+    int g_off[IPT], l_off[IPT];
+    bool inside[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        int it = threadIdx.x + 256 * i;
+        const bool live = it < NITEM;
+        if (!live) it = NITEM - 1;
+        const int pix = it % NPIX, hh = it / NPIX;            // lanes walk pixels: coalesced loads per channel
+        const int pr = pix / PW, pc = pix % PW;
+        const int iy = oy0 - 1 + pr, ix = pc - 1;
+        inside[i] = live && iy >= 0 && iy < W && ix >= 0 && ix < W;
+        const int cy = iy < 0 ? 0 : (iy >= W ? W - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        g_off[i] = (8 * hh * W + cy) * W + cx;                // + (stage * 16 + j) * W * W
+        l_off[i] = live ? pix * 32 + ((hh ^ ((pix >> 3) & 1)) << 4) : -1;
+    }
+    auto load = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rin[i][j] = xi[(int64_t)(st * KC + j) * (W * W) + g_off[i]];
+    };
+    auto store = [&](int buf) {
+        char *sb = sm + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            u32x4 ph, pl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned th, tl;
+                split2h(inside[i] ? rin[i][2 * p] * x_scale : 0.f, inside[i] ? rin[i][2 * p + 1] * x_scale : 0.f, th, tl);
+                ph[p] = th; pl[p] = tl;
+            }
+            if (l_off[i] >= 0) {
+                *reinterpret_cast<u32x4 *>(sb + l_off[i]) = ph;
+                *reinterpret_cast<u32x4 *>(sb + l_off[i] + PLANE) = pl;
+            }
+        }
+    };
+
+    // ---- this wave's column blocks and this lane's pixels --------------------------------------------------------
+    // block b covers strip pixels 32 b .. 32 b + 31 (row-major over R x W); wave w takes blocks w and w + 4
+    int pbase[2];                                             // padded index of the pixel's tap (0, 0) corner
+    bool live_blk[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int blk = wave + 4 * t;
+        live_blk[t] = blk < NBLK;                              // wave-uniform
+        int p = blk * 32 + n;
+        if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
+        pbase[t] = (p / W) * PW + (p % W);
+    }
+    // A fragments: w3[stage][tap][term][oc = n][16], this lane's 16 bytes at channel 8 half
+    const uint16_t *wp = w3 + (int64_t)n * KC + 8 * half;
+    constexpr int W_TERM = COUT * KC, W_TAP = 2 * W_TERM, W_ST = 9 * W_TAP;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Weights.  vmcnt is in order: an MFMA that waits for a weight fragment also waits for every load issued before
+    // it -- including the activation prefetch of the stage (issued at the top, needed only at the end, HBM latency).
+    // So the fragments of taps 0..3 are loaded at the END of the previous stage (older than the prefetch: their
+    // waits cost nothing), and taps 4..8 are loaded two taps ahead of their use: the first wait that drags the
+    // prefetch in comes after four taps (~3000 matrix cycles) of cover.
+    f16x8 wf[9][2];
+#define MIRX_D2H_LOADW(TAP, SRC)                                                                    \
+    {                                                                                              \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                           \
+            wf[TAP][q_] = *reinterpret_cast<const f16x8 *>((SRC) + (TAP) * W_TAP + q_ * W_TERM);   \
+    }
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) MIRX_D2H_LOADW(tap, wp)
+
+#define MIRX_D2H_READB(DST, TAP, T)                                                                 \
+    {                                                                                              \
+        const int pix_ = pbase[T] + ((TAP) / 3) * PW + (TAP) % 3;                                  \
+        const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 3) & 1)) << 4);                      \
+        DST[0] = *reinterpret_cast<const f16x8 *>(pb_);                                            \
+        DST[1] = *reinterpret_cast<const f16x8 *>(pb_ + PLANE);                                    \
+    }
+#define MIRX_D2H_MFMA(T, TAP, B)                                                                    \
+    {                                                                                              \
+        f32x16 c_ = acc[T];                                                                        \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][1], B[0], c_, 0, 0, 0);                \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][0], B[1], c_, 0, 0, 0);                \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][0], B[0], c_, 0, 0, 0);                \
+        acc[T] = c_;                                                                               \
+    }
+    const bool two = live_blk[1];                          // wave-uniform: waves 0..2 own two column blocks
+    load(0);
+    store(0);
+    for (int st = 0; st < NST; ++st) {
+        const int cur = st & 1;
+        __syncthreads();                                   // stage st visible; buffer cur ^ 1 free
+        load(st + 1 < NST ? st + 1 : st);                  // branch-free: the last stage re-loads itself
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = sm + cur * STAGE;
+        const uint16_t *wc = wp + (int64_t)st * W_ST;
+        const uint16_t *wn = wp + (int64_t)(st + 1 < NST ? st + 1 : st) * W_ST;
+        // B fragments are read one (tap, block) unit ahead of the MFMAs that use them
+        f16x8 b0[2], b1[2];
+        MIRX_D2H_READB(b0, 0, 0)
+        if (two) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap >= 2 && tap + 2 < 9) MIRX_D2H_LOADW(tap + 2, wc)
+                MIRX_D2H_READB(b1, tap, 1)
+                __builtin_amdgcn_sched_barrier(0);
+                MIRX_D2H_MFMA(0, tap, b0)
+                if (tap + 1 < 9) MIRX_D2H_READB(b0, tap + 1, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MIRX_D2H_MFMA(1, tap, b1)
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap >= 2 && tap + 2 < 9) MIRX_D2H_LOADW(tap + 2, wc)
+                if (tap + 1 < 9) MIRX_D2H_READB(b1, tap + 1, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                MIRX_D2H_MFMA(0, tap, b0)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) b0[q] = b1[q];
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) MIRX_D2H_LOADW(tap, wn)       // next stage's early taps: older than its prefetch
+        store(cur ^ 1);
+    }
+#undef MIRX_D2H_LOADW
+#undef MIRX_D2H_READB
+#undef MIRX_D2H_MFMA
+
+    // ---- outputs straight from the accumulators: register r = channel 8 (r >> 2) + (r & 3) + 4 half, lane = pixel ----
+    float *oi = out + img * out_bs + (int64_t)oy0 * W;
+    float osc[16], vmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = (wave + 4 * t) * 32 + n;
+        if (live_blk[t] && p < NOUT && oy0 + p / W < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
+                const float v = acc[t][r] * osc[r];
+                vmax = range_max(vmax, v);
+                oi[(int64_t)oc * (W * W) + p] = v;
+            }
+        }
+    }
+    if (out_range) range_publish(out_range, vmax, lane);
+}
+
+template <int W, int R>
+hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
+                      const float *in_range, float *out_range, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * (R + 2) * (W + 2) * 32;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2h<W, R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_conv3x3_d2h<W, R>), dim3((W + R - 1) / R, (unsigned)n), dim3(256), lds, st, x, w2, oscale, out,
+                       out_bs, in_range, reinterpret_cast<unsigned *>(out_range));
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_range, float *out_range, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535 || !in_range || !oscale) return hipErrorInvalidValue;
+    if (side == 56) return launch_d2h<56, 4>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
+    if (side == 28) return launch_d2h<28, 8>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
+    if (side == 14) return launch_d2h<14, 14>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mirx

@@ -55,7 +55,8 @@ __device__ inline void split2(float a, float b, unsigned &h, unsigned &m, unsign
 
 __global__ __launch_bounds__(256, 3) void k_stem_s3(const float *__restrict__ x, const uint16_t *__restrict__ w3,
                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                    int h, int wd, float *__restrict__ y) {
+                                                    int h, int wd, float *__restrict__ y, int64_t y_bs,
+                                                    unsigned *__restrict__ out_range) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *s_in = sm;                    // [2 parity][3][ITH][PH]
     float *s_conv = sm;                  // [OCB][CONV_PITCH], after the K loop
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256, 3) void k_stem_s3(const float *__restrict__ x,
     __syncthreads();
 
     // ---- max-pool 3x3 / 2: only the pooled map goes to HBM ----------------------------------------
-    float *yi = y + (img * 64 + oc0) * (int64_t)ph * pw;
+    float *yi = y + img * y_bs + oc0 * (int64_t)ph * pw;   // y_bs: batch stride (the dense block's buffer)
+    float vmax = 0.f;
     for (int i = threadIdx.x; i < OCB * PTH * 8; i += 256) {
         const int oc = i / (PTH * 8), r = (i / 8) % PTH, q = i % 8;
         const int py = py0 + r, px = px0 + q;
@@ -176,14 +178,16 @@ __global__ __launch_bounds__(256, 3) void k_stem_s3(const float *__restrict__ x,
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, cbase[dy * CTW + dx]);
             yi[((int64_t)oc * ph + py) * pw + px] = m;
+            vmax = range_max(vmax, m);
         }
     }
+    if (out_range) range_publish(out_range, vmax, threadIdx.x & 63);
 }
 
 }  // namespace
 
 hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale, const float *shift, int64_t n, int h,
-                          int wd, float *y, hipStream_t st) {
+                          int wd, float *y, int64_t y_bs, float *out_range, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (n > 65535) return hipErrorInvalidValue;
     const int ph = h / 4, pw = wd / 4;
@@ -193,7 +197,7 @@ hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_stem_s3, dim3((unsigned)tiles, (unsigned)n, 64 / OCB), dim3(256), lds, st, x, w3, scale, shift, h,
-                       wd, y);
+                       wd, y, y_bs, reinterpret_cast<unsigned *>(out_range));
     return hipGetLastError();
 }
 

@@ -646,6 +646,26 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
     return MIRX_OK;
 }
 
+int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale1_or_null,
+                                 const float *shift1_or_null, const void *w2, const float *oscale,
+                                 const float *bias_or_null, int64_t n, int hw, int cout, int relu_out, float *y,
+                                 int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
+                                 float *out_range_or_null, void *stream) {
+    MIRX_CHECK(n >= 0 && hw >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0,
+               "conv1x1_split2h: cin must be a multiple of 16 and cout of 128");
+    MIRX_CHECK((scale1_or_null == nullptr) == (shift1_or_null == nullptr), "conv1x1_split2h: scale and shift go together");
+    MIRX_CHECK(n == 0 || (x && w2 && y && oscale), "conv1x1_split2h: null buffer");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1_split2h: batch stride smaller than the channel prefix");
+    MIRX_CHECK(y_batch_stride >= (int64_t)cout * hw, "conv1x1_split2h: output batch stride smaller than cout * hw");
+    MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && (in_range_or_null || in_kb > 0.f),
+               "conv1x1_split2h: in_ks / in_kb are non-negative; without range slots in_kb is the bound itself");
+    MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
+                               reinterpret_cast<const uint16_t *>(w2), oscale, bias_or_null, n, hw, cout, relu_out, y,
+                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null,
+                               reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream) {
     MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split3: k must be a multiple of 16");
@@ -704,7 +724,30 @@ int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int si
     MIRX_CHECK(side == 56 || side == 28 || side == 14 || side == 7, "conv3x3: side must be 56, 28, 14 or 7");
     MIRX_CHECK(n == 0 || (x && u && out), "conv3x3: null buffer");
     MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3: output batch stride too small");
-    MIRX_HIP(launch_conv3x3_wino(x, u, n, side, out, out_batch_stride, reinterpret_cast<hipStream_t>(stream)));
+    MIRX_HIP(launch_conv3x3_wino(x, u, n, side, out, out_batch_stride, nullptr, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_conv3x3_winograd_nchw_ranged(const float *x, const float *u, int64_t n, int side, float *out,
+                                      int64_t out_batch_stride, float *out_range_or_null, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14 || side == 7, "conv3x3: side must be 56, 28, 14 or 7");
+    MIRX_CHECK(n == 0 || (x && u && out), "conv3x3: null buffer");
+    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3: output batch stride too small");
+    MIRX_HIP(launch_conv3x3_wino(x, u, n, side, out, out_batch_stride, out_range_or_null,
+                                 reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_conv3x3_direct_split2h_nchw(const float *x, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                     int64_t out_batch_stride, const float *in_range, float *out_range_or_null,
+                                     void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_split2h: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_split2h: side must be 56, 28 or 14");
+    MIRX_CHECK(n == 0 || (x && w2 && oscale && out && in_range), "conv3x3_split2h: null buffer");
+    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_split2h: output batch stride too small");
+    MIRX_HIP(launch_conv3x3_d2h(x, reinterpret_cast<const uint16_t *>(w2), oscale, n, side, out, out_batch_stride, in_range,
+                                out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
@@ -836,7 +879,18 @@ int mirx_stem_conv7_bn_relu_pool_split3(const float *x, const void *w3, const fl
     MIRX_CHECK(x && w3 && scale && shift && y && n >= 0 && n <= 65535, "stem_split3: null argument or batch > 65535");
     MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split3: H and W must be multiples of 4");
     MIRX_HIP(launch_stem_s3(x, reinterpret_cast<const uint16_t *>(w3), scale, shift, n, h, wd, y,
-                            reinterpret_cast<hipStream_t>(stream)));
+                            (int64_t)64 * (h / 4) * (wd / 4), nullptr, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
+                                             int64_t n, int h, int wd, float *y, int64_t y_batch_stride,
+                                             float *out_range_or_null, void *stream) {
+    MIRX_CHECK(x && w3 && scale && shift && y && n >= 0 && n <= 65535, "stem_split3: null argument or batch > 65535");
+    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split3: H and W must be multiples of 4");
+    MIRX_CHECK(y_batch_stride >= (int64_t)64 * (h / 4) * (wd / 4), "stem_split3: output batch stride too small");
+    MIRX_HIP(launch_stem_s3(x, reinterpret_cast<const uint16_t *>(w3), scale, shift, n, h, wd, y, y_batch_stride,
+                            out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

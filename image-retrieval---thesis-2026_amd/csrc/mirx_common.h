@@ -93,6 +93,56 @@ __device__ inline double lane_tree_score(const float *__restrict__ q, const floa
     acc = wave_butterfly_sum(acc);
     return METRIC == 0 ? acc : -acc;
 }
+// ---- value ranges that travel with activations (two-fp16-term kernels) ---------------------------------
+// A producer publishes the largest |value| it wrote into one of RANGE_SLOTS floats (slot = workgroup % 64) with an
+// unsigned atomic max: the bit patterns of non-negative floats order like the floats, +inf and NaN sort above every
+// finite value, so a non-finite output makes the consumer's scale NaN and its whole output NaN (loud, never a silently
+// wrong finite number).  A consumer reduces the 64 slots and derives its power-of-two staging scale.
+constexpr int RANGE_SLOTS = 64;
+
+__device__ inline float range_shfl_xor(float v, int off) { return __shfl_xor(v, off, 64); }
+
+__device__ inline float range_max(float m, float v) {
+    // max(m, |v|) that keeps a NaN (fmaxf would drop it)
+    const float a = fabsf(v);
+    return (a > m || a != a) ? a : m;
+}
+
+// the maximum of the 64 slots, the same value in every lane (one wave-wide load)
+__device__ inline float range_read(const float *__restrict__ slots) {
+    unsigned a = __float_as_uint(slots[threadIdx.x & 63]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)a, off, 64);
+        a = o > a ? o : a;
+    }
+    return __uint_as_float(a);
+}
+
+// bound >= every |value|: x_scale = 2^(14 - floor(log2 bound)) puts bound * x_scale in [2^14, 2^15) (fp16 overflows at
+// 65504); inv = 1 / x_scale.  bound == 0 (or subnormal) -> 1; non-finite -> NaN.
+__device__ inline void range_scales(float bound, float &x_scale, float &inv) {
+    const unsigned u = __float_as_uint(bound);
+    const int e = (int)((u >> 23) & 0xffu) - 127;
+    if (!(bound < 3.0e38f) || (u >> 31)) {
+        x_scale = inv = __uint_as_float(0x7fc00000u);
+    } else if (e < -100) {
+        x_scale = inv = 1.f;
+    } else {
+        x_scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+    }
+}
+
+__device__ inline void range_publish(unsigned *__restrict__ slots, float vmax, int lane) {
+    unsigned a = __float_as_uint(vmax);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)a, off, 64);
+        a = o > a ? o : a;
+    }
+    if (lane == 0 && a) atomicMax(slots + (blockIdx.x & (RANGE_SLOTS - 1)), a);
+}
 #endif  // __HIPCC__
 
 }  // namespace mirx

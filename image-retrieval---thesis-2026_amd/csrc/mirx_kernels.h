@@ -26,8 +26,9 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 // k_stem_s3.hip: the same stem on three-term bf16 MFMAs; w3 = pre-split weights [2][11][3][32][16] bf16
+// y_bs = output batch stride in floats (64 * (h/4) * (wd/4) for a packed tensor); out_range: range slots or null
 hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale, const float *shift, int64_t n, int h,
-                          int wd, float *y, hipStream_t st);
+                          int wd, float *y, int64_t y_bs, float *out_range, hipStream_t st);
 
 // ---- k_conv1x1.hip ----------------------------------------------------------------------
 hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
@@ -66,6 +67,12 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
                              const uint16_t *w3, const float *bias, int64_t n, int hw, int cout, int relu_out,
                              float *y, int64_t ybs, hipStream_t st);
 
+// ---- k_conv1x1_h2.hip: the same convolution on two fp16 terms per operand; ranges travel in 64 "range slots" ----
+hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                             const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
+                             int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
+                             float *out_amax, hipStream_t st);
+
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
                             const float *res, const float *gamma, float x_scale, float out_scale, float *y, hipStream_t st);
@@ -77,7 +84,7 @@ hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3
 
 // ---- k_conv3x3.hip ----------------------------------------------------------------------
 hipError_t launch_conv3x3_wino(const float *x, const float *u, int64_t n, int side, float *out, int64_t out_bs,
-                               hipStream_t st);
+                               float *out_range, hipStream_t st);
 // ---- k_conv3x3_s3.hip: the same convolution on three-term bf16 MFMAs (side 56 / 28 / 14) ----------
 hipError_t launch_conv3x3_wino_s3(const float *x, const uint16_t *u3, int64_t n, int side, float *out, int64_t out_bs,
                                   hipStream_t st);
@@ -85,6 +92,11 @@ hipError_t launch_conv3x3_wino_s3(const float *x, const uint16_t *u3, int64_t n,
 // w3 = [8 stages][9 taps][3 terms][32 oc][16 c] bf16
 hipError_t launch_conv3x3_d3(const float *x, const uint16_t *w3, int64_t n, int side, float *out, int64_t out_bs,
                              hipStream_t st);
+
+// ---- k_conv3x3_d2h.hip: the direct implicit GEMM on two fp16 terms per operand; ranges travel in range slots ------
+// w2 = [8 stages][9 taps][2 terms][32 oc][16 c] fp16 (scaled per output channel), oscale = [32] fp32
+hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_range, float *out_range, hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

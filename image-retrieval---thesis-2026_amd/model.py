@@ -204,6 +204,56 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
     return F.conv2d(pooled, tr.conv.weight)
 
 
+def _dense_block_h2(block, buf, cache, brange, lranges, timer=None):
+    """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, h, h] already holds the first block.cin
+    channels and `brange` (64 range slots) bounds them; every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2
+    epilogue; reads brange, publishes the bottleneck's range in its row of `lranges`) -> conv3x3 (reads that row,
+    writes 32 channels into the buffer, folds their range into brange)."""
+    lib = _lib.load()
+    b, _, h, w = buf.shape
+    st = _stream(buf.device)
+    c = block.cin
+    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)
+    for li, name in enumerate(block.keys()):
+        e = cache[name]
+        ev = _timer_start(timer)
+        _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
+                                                    _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, y.shape[1], 1,
+                                                    _ptr(y), y.shape[1] * h * w, _ptr(brange), e["ks"], e["kb"],
+                                                    _ptr(lranges[li]), st), "mirx_conv1x1_bn_relu_split2h")
+        _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
+        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
+        if CONV3X3_KERNEL_H2.get(h, "wino") == "direct2h":
+            _lib.check(lib.mirx_conv3x3_direct_split2h_nchw(_ptr(y), _ptr(e["c3w2"]), _ptr(e["c3osc"]), b, h, dst,
+                                                            block.cout * h * w, _ptr(lranges[li]), _ptr(brange), st),
+                       "mirx_conv3x3_direct_split2h_nchw")
+        else:
+            _lib.check(lib.mirx_conv3x3_winograd_nchw_ranged(_ptr(y), _ptr(e["u"]), b, h, dst, block.cout * h * w,
+                                                             _ptr(brange), st), "mirx_conv3x3_winograd_nchw_ranged")
+        c += GROWTH
+    return buf
+
+
+def _transition_h2(buf, cache, brange, next_buf, next_range, timer=None):
+    """norm + relu + avgpool2 in one pass, then the 1x1 conv on the pooled map (two fp16 terms; the pooled values are
+    averages of relu(bn(x)), so max|scale| * range + max|shift| bounds them) written into the channel prefix of the next
+    block's buffer, whose range slots receive the output range."""
+    lib = _lib.load()
+    b, c, h, w = buf.shape
+    st = _stream(buf.device)
+    pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
+    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled),
+                                         st), "mirx_bn_relu_avgpool2")
+    hw2 = (h // 2) * (w // 2)
+    ev = _timer_start(timer)
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(pooled), c * hw2, c, None, None, _ptr(cache["w2"]), _ptr(cache["osc"]),
+                                                None, b, hw2, c // 2, 0, _ptr(next_buf), next_buf.shape[1] * hw2,
+                                                _ptr(brange), cache["ks"], cache["kb"], _ptr(next_range), st),
+               "mirx_conv1x1_bn_relu_split2h")
+    _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2))
+    return next_buf
+
+
 class _Transition(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__()
@@ -275,6 +325,20 @@ def _conv3x3_weights_split3(w):
     return t.permute(2, 4, 0, 1, 3).contiguous()
 
 
+def _conv3x3_weights_split2h(w):
+    """conv2 weights [32, 128, 3, 3] -> (w2, oscale): the two fp16 terms of W[oc] * ws[oc] (ws a power of two per output
+    channel) laid out for mirx_conv3x3_direct_split2h_nchw: [stage = c // 16][tap = 3 ky + kx][term][oc][c % 16] fp16, and
+    oscale = 1 / ws fp32 [32]."""
+    w = w.detach().float()
+    oc, cin = w.shape[0], w.shape[1]
+    ws = _pow2_row_scales(w.reshape(oc, -1))
+    wf = w * ws.view(-1, 1, 1, 1)
+    h = wf.to(torch.float16)
+    lo = (wf - h.float()).to(torch.float16)
+    t = torch.stack([h, lo], 0).reshape(2, oc, cin // 16, 16, 9)           # [term, oc, stage, c % 16, tap]
+    return t.permute(2, 4, 0, 1, 3).contiguous(), (1.0 / ws).contiguous()
+
+
 def _stem_weights_split3(w):
     """conv0 weights [64, 3, 7, 7] -> the three bf16 terms laid out for mirx_stem_conv7_bn_relu_pool_split3:
     [2 oc blocks][11 steps][term][32 oc][16 k]; k = 8 g + i of step s is row (c, ky) = divmod(2 s + g, 7) and
@@ -306,6 +370,31 @@ def _split3_weights(w):
     return t.permute(1, 3, 0, 2, 4).contiguous()
 
 
+def _pow2_row_scales(w):
+    """Per output row of w [cout, k]: the power of two that puts the row's largest |w| in [2^13, 2^14) (so that the low
+    fp16 term of all but vanishing weights stays a normal number); rows of zeros (or non-finite rows) get 1."""
+    amax = w.abs().amax(dim=1)
+    ok = torch.isfinite(amax) & (amax > 0)
+    e = torch.floor(torch.log2(torch.where(ok, amax, torch.ones_like(amax))))
+    # floor(log2) of an fp32 can be off by one at exact powers of two after rounding: fix up
+    e = torch.where(torch.exp2(e) > amax, e - 1, e)
+    e = torch.where(torch.exp2(e + 1) <= amax, e + 1, e)
+    return torch.where(ok, torch.exp2(13 - e), torch.ones_like(amax))
+
+
+def _split2h_weights(w):
+    """[cout, cin] fp32 -> (w2, oscale): the two fp16 terms of W[o, :] * ws[o] (ws a power of two per output row),
+    laid out for mirx_conv1x1_bn_relu_split2h: [cout // 128][cin // 16][2][128][16] fp16, and oscale = 1 / ws fp32."""
+    w = w.detach().float()
+    ws = _pow2_row_scales(w)
+    wf = w * ws[:, None]
+    h = wf.to(torch.float16)
+    lo = (wf - h.float()).to(torch.float16)
+    cout, cin = w.shape
+    t = torch.stack([h, lo], 0).reshape(2, cout // 128, 128, cin // 16, 16)
+    return t.permute(1, 3, 0, 2, 4).contiguous(), (1.0 / ws).contiguous()
+
+
 def _bn_affine(bn):
     """Eval-mode BatchNorm as y = x*scale + shift (fp32)."""
     scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -322,6 +411,10 @@ def _stream(dev):
 
 
 CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
+# Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations in "range slots" (include/mirx.h,
+# mirx_conv1x1_bn_relu_split2h); kernels per map side must publish ranges: "direct2h" or "wino" (fp32 Winograd).
+SPLIT2H_DENSENET = True
+CONV3X3_KERNEL_H2 = {56: "direct2h", 28: "direct2h", 14: "direct2h", 7: "wino"}
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
@@ -575,6 +668,24 @@ class DenseNet121(nn.Module):
         return torch.flatten(x, 1)
 
     # -- MI355X inference path -------------------------------------------------------------------
+    # The folded / pre-split weights are derived from the parameters and BatchNorm buffers; they are rebuilt whenever
+    # any of those changed: tensor versions are summed on every forward (in-place edits, load_state_dict through a
+    # parent module and copy_ all bump them), device moves and dtype casts arrive through _apply.
+    def _weights_version(self):
+        watch = self.__dict__.get("_mirx_watch")
+        if watch is None:
+            f = self.densenet121[0]
+            watch = list(f.parameters()) + list(f.buffers())
+            self.__dict__["_mirx_watch"] = watch
+        return sum(t._version for t in watch)
+
+    def _cache(self):
+        ver = self._weights_version()
+        if self._infer_cache is None or self._infer_cache.get("_version") != ver:
+            self._prepare_inference()
+            self._infer_cache["_version"] = ver
+        return self._infer_cache
+
     def train(self, mode=True):
         self._infer_cache = None
         return super().train(mode)
@@ -585,6 +696,7 @@ class DenseNet121(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._infer_cache = None
+        self.__dict__.pop("_mirx_watch", None)
         return super()._apply(fn, *a, **k)
 
     def _prepare_inference(self):
@@ -620,7 +732,9 @@ class DenseNet121(nn.Module):
         lib = _lib.load()
         x = x.contiguous().float()
         b, _, h, w = x.shape
-        cache = self._infer_cache or self._prepare_inference()
+        cache = self._cache()
+        if self._h2_ok(x):
+            return self._features_h2(x, cache)
         if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
             sc, sh = cache["norm0"]
             y = torch.empty((b, INIT_FEATURES, h // 4, w // 4), dtype=torch.float32, device=x.device)
@@ -647,10 +761,71 @@ class DenseNet121(nn.Module):
                                       nxt.cout if nxt is not None else None)
         return x
 
+    def _h2_ok(self, x):
+        """The two-fp16-term path covers the geometry of the reference's 224 x 224 evaluation (maps 56 / 28 / 14 / 7)."""
+        return (SPLIT2H_DENSENET and self.use_hip_stem and self.use_hip_conv1x1 and self.use_hip_conv3x3 and SPLIT3_STEM
+                and x.shape[-1] == 224 and x.shape[-2] == 224 and 0 < x.shape[0] <= 65535)
+
+    def _prepare_h2(self, cache):
+        """Per layer: conv1 (norm2 folded) and conv2 as two fp16 terms with per-output-channel scales, and the host
+        constants max |norm1 scale| / max |norm1 shift| that turn the buffer's published range into a bound."""
+        f = self.densenet121[0]
+        h2 = {}
+        for name, m in f.named_children():
+            if name.startswith("denseblock"):
+                blk = {}
+                for lname, layer in m.items():
+                    sc1, sh1, w1, b1 = cache[name][lname][0], cache[name][lname][1], cache[name][lname][2], cache[name][lname][3]
+                    w2, osc = _split2h_weights(w1.view(w1.shape[0], w1.shape[1]))
+                    c3w2, c3osc = _conv3x3_weights_split2h(layer.conv2.weight)
+                    blk[lname] = {"sc1": sc1, "sh1": sh1, "b1": b1, "w2": w2, "osc": osc, "c3w2": c3w2, "c3osc": c3osc,
+                                  "u": cache[name][lname][6][0], "ks": float(sc1.abs().max()), "kb": float(sh1.abs().max())}
+                h2[name] = blk
+            elif name.startswith("transition"):
+                sc, sh = cache[name][0], cache[name][1]
+                wt = m.conv.weight.detach().float()
+                w2, osc = _split2h_weights(wt.view(wt.shape[0], wt.shape[1]))
+                h2[name] = {"sc": sc, "sh": sh, "w2": w2, "osc": osc, "ks": float(sc.abs().max()), "kb": float(sh.abs().max())}
+        if "conv0_w3" not in cache:
+            cache["conv0_w3"] = _stem_weights_split3(f.conv0.weight)
+        cache["h2"] = h2
+        return h2
+
+    def _features_h2(self, x, cache):
+        """-> feature map before norm5 [B, 1024, 7, 7]; every convolution on the matrix pipe with two fp16 terms per
+        operand (stem: three bf16 terms, 7 x 7 maps' 3x3 convs: fp32 Winograd), ranges carried in range slots."""
+        f = self.densenet121[0]
+        lib = _lib.load()
+        h2 = cache.get("h2") or self._prepare_h2(cache)
+        x = x.contiguous().float()
+        b = x.shape[0]
+        dev = x.device
+        st = _stream(dev)
+        blocks = [(n, m) for n, m in f.named_children() if n.startswith("denseblock")]
+        trans = [n for n, _ in f.named_children() if n.startswith("transition")]
+        nlayers = sum(len(m) for _, m in blocks)
+        ranges = torch.zeros((len(blocks) + nlayers, 64), dtype=torch.float32, device=dev)      # one fill per forward
+        side = 56
+        buf = torch.empty((b, blocks[0][1].cout, side, side), dtype=torch.float32, device=dev)
+        sc, sh = cache["norm0"]
+        _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3_into(_ptr(x), _ptr(cache["conv0_w3"]), _ptr(sc), _ptr(sh), b, 224,
+                                                                224, _ptr(buf), blocks[0][1].cout * side * side,
+                                                                _ptr(ranges[0]), st), "mirx_stem_split3_into")
+        row = len(blocks)
+        for k, (name, blk) in enumerate(blocks):
+            _dense_block_h2(blk, buf, h2[name], ranges[k], ranges[row:row + len(blk)], self.conv1x1_timer)
+            row += len(blk)
+            if k + 1 < len(blocks):
+                side //= 2
+                nxt = torch.empty((b, blocks[k + 1][1].cout, side, side), dtype=torch.float32, device=dev)
+                _transition_h2(buf, h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
+                buf = nxt
+        return buf
+
     def _head_fused(self, fmap, normalize):
         f = self.densenet121[0]
         lib = _lib.load()
-        sc, sh = (self._infer_cache or self._prepare_inference())["norm5"]
+        sc, sh = self._cache()["norm5"]
         fmap = fmap.contiguous()
         b, c, h, w = fmap.shape
         out = torch.empty((b, c), dtype=torch.float32, device=fmap.device)

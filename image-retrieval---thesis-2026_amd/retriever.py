@@ -5,7 +5,8 @@ Mirrors (paths into /root/reference):
   MilvusRetriever.search / batch_search             milvus/milvus_retrieval.py:15-140
   get_model_and_transform                           milvus/milvus_retrieval.py:143-200
   collection.insert([paths, labels, embeddings])    ingest_embeddings.py:399-411
-  search_collection (NIH)                           nih_zilliz_utils.py:254-280
+  search_by_embeddings                              retrieval_analysis/milvus_adapter.py:218-275 (mirx.adapter)
+  NIH helpers                                       mirx.nih (nih_zilliz_utils.py)
 The "server" is a device-resident FlatIndex (libmirx); searches are EXACT (the reference's
 IVF_FLAT nlist=1024 / nprobe=10 index is approximate, milvus_setup.py:191-213) and
 `search_params` / `nprobe` are accepted and ignored.  Metadata (image_path, label) stays on
@@ -56,17 +57,21 @@ class Collection:
     """The slice of pymilvus.Collection the reference uses: insert / flush / load / search /
     num_entities / name / description, backed by a FlatIndex."""
 
-    def __init__(self, name, dim, description="", metric_type="COSINE", device=None, extra_fields=()):
+    def __init__(self, name, dim, description="", metric_type="COSINE", device=None, extra_fields=(), has_label=True):
         self.name = name
         self.description = description
         self.dim = dim
         self.metric_type = metric_type
-        self.schema = ["id", "image_path", "label", "embedding"] + list(extra_fields)
+        # column order of insert(): the default schema is id, image_path, label, embedding (milvus_setup.py:169-176)
+        # followed by any extra scalar fields; the NIH schema (nih_zilliz_utils.py:149-156, has_label=False) is id,
+        # image_path, <extra fields>, embedding
+        if has_label:
+            self.schema = ["id", "image_path", "label", "embedding"] + list(extra_fields)
+        else:
+            self.schema = ["id", "image_path"] + list(extra_fields) + ["embedding"]
         self._device = device
         self._index = None
-        self._meta = {"image_path": [], "label": []}
-        for f in extra_fields:
-            self._meta[f] = []
+        self._meta = {f: [] for f in self.schema if f not in ("id", "embedding")}
 
     def _ensure(self):
         if self._index is None:
@@ -95,20 +100,22 @@ class Collection:
         return None
 
     def insert(self, columns):
-        """columns = [image_paths, labels, embeddings] (ingest_embeddings.py:402-408), plus one
-        list per extra field.  Returns the assigned ids (auto_id: previous size + i)."""
-        paths, labels, emb = columns[0], columns[1], columns[2]
+        """columns = one list per schema field after `id`, in schema order: [image_paths, labels, embeddings]
+        (ingest_embeddings.py:402-408) for the default schema.  Returns the assigned ids (auto_id: previous size + i)."""
+        fields = self.schema[1:]
+        if len(columns) != len(fields):
+            raise ValueError(f"expected {len(fields)} columns ({', '.join(fields)}), got {len(columns)}")
+        cols = dict(zip(fields, columns))
+        emb = cols.pop("embedding")
         emb = torch.as_tensor(np.asarray(emb, dtype=np.float32) if not torch.is_tensor(emb) else emb)
         if emb.dim() != 2 or emb.shape[1] != self.dim:
             raise ValueError(f"embedding dimension mismatch: expected {self.dim}, got {tuple(emb.shape)}")
-        if not (len(paths) == len(labels) == emb.shape[0]):
+        if any(len(c) != emb.shape[0] for c in cols.values()):
             raise ValueError("column lengths differ")
         first = self.num_entities
         self._ensure().add(emb)
-        self._meta["image_path"].extend(str(p) for p in paths)
-        self._meta["label"].extend(labels)
-        for f, col in zip(self.schema[4:], columns[3:]):
-            self._meta[f].extend(col)
+        for f, col in cols.items():
+            self._meta[f].extend((str(p) for p in col) if f == "image_path" else col)
         return list(range(first, first + emb.shape[0]))
 
     def search(self, data, anns_field="embedding", param=None, limit=10, output_fields=None, exclude_ids=None):
@@ -215,12 +222,19 @@ class MilvusManager:
             self.load_collection(model_type)
 
 
-def default_transform(img_size=224):
-    """Resize(shorter side) -> CenterCrop -> ToTensor -> Normalize(ImageNet), the pipeline of
-    milvus_retrieval.py:176-198 without torchvision (PIL + torch only)."""
-    resize = {448: 512, 384: 432}.get(img_size, 256)
-    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
-    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+SIGLIP_MEAN, SIGLIP_STD = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)
+
+
+def default_transform(img_size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, resize=None):
+    """convert('RGB') -> Resize(shorter side) -> CenterCrop -> ToTensor -> Normalize(mean, std): the pipeline of
+    milvus_retrieval.py:176-198 without torchvision (PIL + torch only).  Resize defaults follow the reference
+    (448 -> 512, 384 -> 432, otherwise 256); MedSigLIP normalises with mean = std = 0.5 (milvus_retrieval.py:177-178),
+    every other model with the ImageNet statistics."""
+    if resize is None:
+        resize = {448: 512, 384: 432}.get(img_size, 256)
+    mean = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
 
     def tf(img):
         from PIL import Image
@@ -284,6 +298,9 @@ class MilvusRetriever:
             self.load_collection()
         if metric_type not in ("COSINE", "IP", "L2"):
             raise ValueError(f"Unknown metric type: {metric_type}")
+        if metric_type != self.collection.metric_type and {metric_type, self.collection.metric_type} != {"COSINE", "IP"}:
+            # Milvus rejects a search whose metric differs from the index's (milvus_retrieval.py:75-86)
+            raise ValueError(f"metric type not match: index has {self.collection.metric_type}, search asked {metric_type}")
         hits = self.collection.search(data=query_embedding, anns_field="embedding", param=search_params,
                                       limit=top_k, output_fields=["image_path", "label"])[0]
         return [self._format(h, metric_type) for h in hits], query_embedding
@@ -307,8 +324,25 @@ class MilvusRetriever:
         all_hits = self.collection.search(data=emb, limit=top_k, output_fields=["image_path", "label"])
         return [[self._format(h, self.collection.metric_type) for h in hits] for hits in all_hits]
 
-    def search_by_embeddings(self, query_embeddings, top_k=10, exclude_ids=None):
-        """Batch form in the shape of retrieval_analysis/milvus_adapter.py:218-275."""
+    def adapter(self, name=None):
+        """This retriever's collection seen through retrieval_analysis' MilvusCollectionAdapter (mirx.adapter)."""
+        from .adapter import MilvusCollectionAdapter, MilvusCollectionConfig
+        if self.collection is None:
+            self.load_collection()
+        return MilvusCollectionAdapter(MilvusCollectionConfig(name=name or self.model_type,
+                                                              collection_name=self.collection.name),
+                                       collection=self.collection)
+
+    def search_by_embeddings(self, queries, query_embeddings, top_k, search_params=None, reranker=None,
+                             exclude_self=True, metadata_fields=None, batch_size=None):
+        """retrieval_analysis/milvus_adapter.py:218-275, same arguments and return type (list[SearchResult]): one
+        batched exact search; self dropped by image_path after fetching top_k + 1; `reranker.rerank(query, results)`
+        applied before the cut to top_k."""
+        return self.adapter().search_by_embeddings(queries, query_embeddings, top_k, search_params, reranker,
+                                                   exclude_self, metadata_fields, batch_size)
+
+    def search_ids(self, query_embeddings, top_k=10, exclude_ids=None):
+        """Device-side batch form (no reference counterpart): -> best-first dicts per query, self excluded by id."""
         if self.collection is None:
             self.load_collection()
         hits = self.collection.search(data=query_embeddings, limit=top_k, output_fields=["image_path", "label"],
@@ -316,17 +350,10 @@ class MilvusRetriever:
         return [[self._format(h, self.collection.metric_type) for h in hs] for hs in hits]
 
 
-def search_collection(collection, query_vector, top_k, nprobe=16):
-    """nih_zilliz_utils.search_collection: hits as dicts with `score` and the stored fields."""
-    fields = [f for f in ("image_path", "image_name", "label_text", "label_vector") if f in collection._meta]
-    hits = collection.search(data=[query_vector], limit=top_k, output_fields=fields)[0]
-    out = []
-    for h in hits:
-        d = {"id": h.id, "score": float(h.distance)}
-        for f in fields:
-            d[f] = h.entity.get(f)
-        out.append(d)
-    return out
+def search_collection(collection, query_vector, top_k, nprobe=10):
+    """nih_zilliz_utils.search_collection (lives in mirx.nih with the other NIH helpers)."""
+    from .nih import search_collection as _sc
+    return _sc(collection, query_vector, top_k, nprobe)
 
 
 def get_model_and_transform(model_type, model_weights, embedding_dim, device):
@@ -341,4 +368,6 @@ def get_model_and_transform(model_type, model_weights, embedding_dim, device):
         model.load_state_dict(checkpoint, strict=False)
     model.eval()
     model.to(device)
+    if model_type == "medsiglip":                  # SigLIP normalisation (milvus_retrieval.py:176-181)
+        return model, default_transform(img_size, SIGLIP_MEAN, SIGLIP_STD)
     return model, default_transform(img_size)

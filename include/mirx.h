@@ -172,6 +172,49 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
                                 void *stream);
 
 /*
+ * mirx_conv1x1_bn_relu_split3 with TWO fp16 terms per operand (three MFMAs per product block instead of six).  fp16
+ * has 5 exponent bits, so the range of the input travels with it: `in_range_or_null` = device fp32 [64] "range slots"
+ * whose maximum bounds |x| over the channel prefix the kernel reads (every mirx kernel that writes into a dense
+ * block's buffer publishes the largest |value| it wrote there, unsigned atomic max on the float bits; the caller
+ * zeroes the slots once per forward); the kernel stages act_in(x) * 2^s with
+ *     bound = in_ks * max(slots) + in_kb         (in_ks = max |scale1|, in_kb = max |shift1|; 1, 0 without prologue;
+ *                                                 slots NULL: bound = in_kb, a caller-proved constant)
+ * and s chosen so that bound * 2^s is in [2^14, 2^15).  A non-finite range makes the whole output NaN (never a silently
+ * wrong finite value).  w2 = device fp16 [cout / 128][cin / 16][2][128][16]: the two terms of W[co, k] * ws[co], ws a
+ * power of two per output channel (mirx.model._split2h_weights); oscale = device fp32 [cout] = 1 / ws.
+ * `out_range_or_null`: range slots that receive the largest |y| written (device fp32 [64], atomic max).
+ * Otherwise the contract of mirx_conv1x1_bn_relu_split3 (reference: the conv1 / transition conv calls inside
+ * torchvision densenet121, model.py:53-60).
+ */
+int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale1_or_null,
+                                 const float *shift1_or_null, const void *w2, const float *oscale,
+                                 const float *bias_or_null, int64_t n, int hw, int cout, int relu_out, float *y,
+                                 int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
+                                 float *out_range_or_null, void *stream);
+
+/*
+ * Range-publishing forms of the DenseNet producers (the two-fp16-term kernels need the range of what they read; see
+ * mirx_conv1x1_bn_relu_split2h).  `out_range_or_null` = device fp32 [64] range slots of the destination buffer; every
+ * workgroup folds the largest |value| it wrote into slot (workgroup % 64) with an unsigned atomic max.
+ *   mirx_stem_conv7_bn_relu_pool_split3_into: mirx_stem_conv7_bn_relu_pool_split3 writing image b at y + b *
+ *       y_batch_stride (the channel prefix of dense block 1's buffer: no copy).
+ *   mirx_conv3x3_winograd_nchw_ranged: mirx_conv3x3_winograd_nchw + range.
+ *   mirx_conv3x3_direct_split2h_nchw: the 3x3 conv (128 -> 32, pad 1) as a direct implicit GEMM on two fp16 terms per
+ *       operand (three MFMAs per product block); `in_range` = range slots of x (published by the 1x1 conv that wrote it);
+ *       w2 = device fp16 [8 stages][9 taps][2 terms][32 oc][16 c], scaled per output channel by a power of two
+ *       (mirx.model._conv3x3_weights_split2h), oscale = device fp32 [32] = 1 / that scale.  side 56 / 28 / 14.
+ * (reference: the conv0 / conv2 calls inside torchvision densenet121, model.py:53-60)
+ */
+int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
+                                             int64_t n, int h, int w, float *y, int64_t y_batch_stride,
+                                             float *out_range_or_null, void *stream);
+int mirx_conv3x3_winograd_nchw_ranged(const float *x, const float *u, int64_t n, int side, float *out,
+                                      int64_t out_batch_stride, float *out_range_or_null, void *stream);
+int mirx_conv3x3_direct_split2h_nchw(const float *x, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                     int64_t out_batch_stride, const float *in_range, float *out_range_or_null,
+                                     void *stream);
+
+/*
  * Linear layer of the token-major backbones (replaces the nn.Linear calls inside the timm / transformers
  * models the reference instantiates: model.py:448-494 DinoV2, model.py:87-118 ConvNeXtV2,
  * model.py:536-638 MedSigLIP vision tower), fp32-grade on the bf16 matrix pipe with three bf16 terms per operand:

@@ -105,3 +105,66 @@ def test_retriever_protocol(tmp_path):
     with pytest.raises(ValueError):
         col.insert([["a"], ["b"], [[0.0] * 7]])
     mgr.disconnect()
+
+
+def test_search_by_embeddings_reference_signature():
+    """retrieval_analysis/milvus_adapter.py:218-275: (queries, query_embeddings, top_k, search_params, reranker,
+    exclude_self, metadata_fields, batch_size) -> list[SearchResult]; self dropped by image_path after fetching
+    top_k + 1; the reranker hook runs before the cut; ids equal the oracle's exact ranking."""
+    from mirx.adapter import IdentityReranker, QueryRecord, RetrievedItem, SearchResult
+    from mirx.retriever import MilvusManager, MilvusRetriever
+    mgr = MilvusManager(dataset="isic")
+    assert mgr.connect()
+    col = mgr.create_collection("convnextv2", drop_old=True)
+    n, d = 3000, 1024
+    g = torch.nn.functional.normalize(torch.randn(n, d, generator=torch.Generator().manual_seed(5)), dim=1)
+    paths = [f"/isic/im_{i}.jpg" for i in range(n)]
+    labels = [f"c{i % 7}" for i in range(n)]
+    col.insert([paths, labels, g])
+    r = MilvusRetriever(mgr, "convnextv2", None, None)
+    qi = [5, 17, 2999, 1234, 42]
+    queries = [QueryRecord(image_path=paths[i], label=labels[i]) for i in qi]
+    emb = g[qi].numpy().tolist()
+    res = r.search_by_embeddings(queries, emb, top_k=6, search_params={"params": {"nprobe": 10}}, batch_size=2)
+    assert len(res) == len(qi) and all(isinstance(x, SearchResult) for x in res)
+    o_s, o_i = OS.topk(g[qi].numpy(), g.numpy(), 6, exclude=np.array(qi))
+    for x, q, ids, sc, e in zip(res, queries, o_i, o_s, emb):
+        assert x.query is q and x.query_source == "convnextv2" and x.query_embedding == e
+        assert all(isinstance(it, RetrievedItem) for it in x.retrieved)
+        assert [it.id for it in x.retrieved] == ids.tolist()
+        assert [it.image_path for it in x.retrieved] == [paths[i] for i in ids]
+        assert [it.label for it in x.retrieved] == [labels[i] for i in ids]
+        assert [it.score for it in x.retrieved] == pytest.approx(sc.tolist(), abs=1e-6)
+        assert all(it.distance == it.score and it.raw["id"] == it.id for it in x.retrieved)
+    # exclude_self=False keeps the query's own row first
+    keep = r.search_by_embeddings(queries[:1], emb[:1], top_k=3, exclude_self=False)[0]
+    assert keep.retrieved[0].id == qi[0] and len(keep.retrieved) == 3
+
+    class _Reverse:                                   # the hook sees the self-filtered top_k + 1 list, cut comes after
+        calls = []
+
+        def rerank(self, query, results):
+            self.calls.append((query.image_path, len(results)))
+            return list(results)[::-1]
+
+    rr = _Reverse()
+    rev = r.search_by_embeddings(queries[:2], emb[:2], top_k=6, reranker=rr)
+    assert rr.calls == [(paths[5], 6), (paths[17], 6)]
+    assert [it.id for it in rev[0].retrieved] == o_i[0].tolist()[::-1]
+    same = r.search_by_embeddings(queries[:2], emb[:2], top_k=6, reranker=IdentityReranker())
+    assert [it.id for it in same[1].retrieved] == o_i[1].tolist()
+    assert r.search_by_embeddings([], [], top_k=3) == []
+    with pytest.raises(ValueError):
+        r.search_by_embeddings(queries, emb[:2], top_k=3)
+    ad = r.adapter()
+    assert ad.fetch_record_by_image_path(paths[9])["label"] == labels[9]
+    np.testing.assert_allclose(ad.fetch_record_by_image_path(paths[9])["embedding"], g[9].numpy(), atol=0)
+    got = ad.fetch_records_by_image_paths([paths[3], paths[2500], "/nope"], include_embedding=True)
+    assert set(got) == {paths[3], paths[2500]} and np.array_equal(got[paths[2500]]["embedding"], g[2500].numpy())
+    assert ad.fetch_record_by_image_path("/nope") is None and len(ad.list_image_paths()) == n
+    one = ad.search_by_embedding(queries[3], emb[3], top_k=4)
+    assert [it.id for it in one.retrieved] == o_i[3][:4].tolist()
+    # a metric that differs from the collection's is rejected like Milvus does
+    with pytest.raises(ValueError):
+        MilvusRetriever(mgr, "convnextv2", torch.nn.Identity(), lambda im: torch.zeros(3, 4, 4)).search(
+            __import__("PIL.Image", fromlist=["x"]).new("RGB", (8, 8)), top_k=3, metric_type="L2")

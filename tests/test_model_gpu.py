@@ -305,3 +305,159 @@ def test_split3_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu):
     err = float((y.double() - want).abs().max())
     assert err < 3e-6 * max(1.0, float(want.abs().max())), err
     assert bool((ybuf[:, cout:] == -5.0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw,n,prologue,relu,mag", [(256, 128, 196, 3, True, True, 1.0), (512, 128, 49, 5, True, True, 40.0),
+                                                             (1024, 512, 49, 2, False, False, 1e-3), (64, 128, 3136, 1, True, True, 300.0),
+                                                             (992, 128, 37, 3, True, True, 1.0)])
+def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
+    """mirx_conv1x1_bn_relu_split2h (two fp16 terms per operand, three MFMAs per product; the input range read from
+    range slots) against a float64 restatement: fp32-grade (3e-6 relative to the largest output) at any input
+    magnitude, output range published exactly, bytes beyond the channel prefix untouched."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(cin + hw)
+    ctot = cin + 32
+    buf = torch.randn(n, ctot, hw, generator=g, device=dev) * mag
+    w = torch.randn(cout, cin, generator=g, device=dev) / cin ** 0.5
+    w[3] *= 1e-4                                                    # one output channel with tiny weights: its own scale
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3 * mag
+    bias = torch.randn(cout, generator=g, device=dev) * mag
+    w2, osc = _split2h_weights(w)
+    assert w2.shape == (cout // 128, cin // 16, 2, 128, 16) and w2.dtype == torch.float16 and osc.shape == (cout,)
+    slots_in = torch.zeros(64, device=dev)
+    slots_in[cin % 64] = float(buf[:, :cin].abs().max())            # what the producers of the prefix published
+    slots_out = torch.zeros(64, device=dev)
+    ybuf = torch.full((n, cout + 8, hw), -5.0, device=dev)
+    y = ybuf[:, :cout]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    ks, kb = (float(sc.abs().max()), float(sh.abs().max())) if prologue else (1.0, 0.0)
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
+                                                vp(sh) if prologue else None, vp(w2), vp(osc), vp(bias), n, hw, cout,
+                                                1 if relu else 0, vp(y), (cout + 8) * hw, vp(slots_in), ks, kb,
+                                                vp(slots_out), None), "split2h")
+    torch.cuda.synchronize()
+    xin = buf[:, :cin].double()
+    if prologue:
+        xin = torch.relu(xin * sc.double()[None, :, None] + sh.double()[None, :, None])
+    want = torch.einsum("oc,bcp->bop", w.double(), xin) + bias.double()[None, :, None]
+    if relu:
+        want = torch.relu(want)
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(mag, float(want.abs().max())), err
+    assert bool((ybuf[:, cout:] == -5.0).all())
+    assert float(slots_out.max()) == float(y.abs().max())
+    # a non-finite range poisons the output instead of returning finite garbage
+    slots_in[0] = float("inf")
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
+                                                vp(sh) if prologue else None, vp(w2), vp(osc), vp(bias), n, hw, cout,
+                                                1 if relu else 0, vp(y), (cout + 8) * hw, vp(slots_in), ks, kb, None, None),
+               "split2h")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(y).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,batch,mag", [(56, 3, 1.7), (28, 5, 60.0), (14, 9, 1e-3), (14, 1, 1.7)])
+def test_direct_split2h_conv3x3_matches_direct_conv(side, batch, mag):
+    """mirx_conv3x3_direct_split2h_nchw (implicit GEMM on two fp16 terms per operand; input range from range slots,
+    per-output-channel weight scales) against a float64 direct convolution: 3e-6 of the largest output at any input
+    magnitude; the output range is published exactly; neighbours of the channel slice untouched."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _conv3x3_weights_split2h
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side + 300)
+    x = torch.relu(torch.randn(batch, 128, side, side, generator=g, device=dev)) * mag
+    w = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    w[5] *= 3e-4                                                    # an output channel with tiny weights: its own scale
+    buf = torch.full((batch, 96, side, side), 7.0, device=dev)
+    c0 = 40
+    w2, osc = _conv3x3_weights_split2h(w)
+    assert w2.shape == (8, 9, 2, 32, 16) and w2.dtype == torch.float16 and osc.shape == (32,)
+    rin = torch.zeros(64, device=dev)
+    rin[11] = float(x.max())
+    rout = torch.zeros(64, device=dev)
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    _lib.check(lib.mirx_conv3x3_direct_split2h_nchw(vp(x), vp(w2), vp(osc), batch, side, vp(buf, 4 * c0 * side * side),
+                                                    96 * side * side, vp(rin), vp(rout), None), "conv3x3_split2h")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, padding=1)
+    got = buf[:, c0:c0 + 32].double().cpu()
+    assert float((got - want).abs().max()) < 3e-6 * float(want.abs().max())
+    # the tiny-weight channel keeps its own relative accuracy
+    assert float((got[:, 5] - want[:, 5]).abs().max()) < 1e-5 * float(want[:, 5].abs().max())
+    assert bool((buf[:, :c0] == 7.0).all()) and bool((buf[:, c0 + 32:] == 7.0).all())      # neighbours untouched
+    assert float(rout.max()) == float(buf[:, c0:c0 + 32].abs().max())
+    assert lib.mirx_conv3x3_direct_split2h_nchw(vp(x), vp(w2), vp(osc), batch, 7, vp(buf), 96 * side * side, vp(rin), None,
+                                                None) == -1
+
+
+@pytest.mark.gpu
+def test_ranged_producers_publish_exact_ranges(model_and_sd):
+    """The stem written straight into a wider block buffer and the fp32 Winograd conv publish the largest |value| they
+    wrote into the destination's range slots (what the two-fp16-term consumers scale by)."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _bn_affine, _stem_weights_split3, _winograd_weights
+    m, sd = model_and_sd
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    f = m.densenet121[0]
+    sc, sh = _bn_affine(f.norm0)
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(4)).to(dev) * 2.0
+    w3 = _stem_weights_split3(f.conv0.weight)
+    packed = torch.empty((3, 64, 56, 56), device=dev)
+    _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3(vp(x), vp(w3), vp(sc), vp(sh), 3, 224, 224, vp(packed), None), "stem")
+    wide = torch.full((3, 96, 56, 56), -3.0, device=dev)
+    slots = torch.zeros(64, device=dev)
+    _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3_into(vp(x), vp(w3), vp(sc), vp(sh), 3, 224, 224, vp(wide), 96 * 3136,
+                                                            vp(slots), None), "stem_into")
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, :64], packed) and bool((wide[:, 64:] == -3.0).all())
+    assert float(slots.max()) == float(packed.max())
+    for side, batch in ((7, 5), (28, 2)):
+        xx = torch.randn(batch, 128, side, side, generator=torch.Generator().manual_seed(side)).to(dev)
+        w = torch.randn(32, 128, 3, 3, generator=torch.Generator().manual_seed(1)).to(dev) * 0.05
+        a = torch.empty((batch, 32, side, side), device=dev)
+        b = torch.empty_like(a)
+        slots.zero_()
+        u = _winograd_weights(w)
+        _lib.check(lib.mirx_conv3x3_winograd_nchw(vp(xx), vp(u), batch, side, vp(a), 32 * side * side, None), "wino")
+        _lib.check(lib.mirx_conv3x3_winograd_nchw_ranged(vp(xx), vp(u), batch, side, vp(b), 32 * side * side, vp(slots), None),
+                   "wino_ranged")
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and float(slots.max()) == float(a.abs().max())
+
+
+@pytest.mark.gpu
+def test_split2h_path_matches_oracle_and_legacy(model_and_sd):
+    """The two-fp16-term DenseNet path (default at 224 x 224) against the CPU restatement (1e-5 on unit-norm
+    embeddings) and against the three-bf16-term path of round 1 on the same weights; inputs of very different
+    magnitudes (the ranges travel with the data); rows independent of what else is in the batch."""
+    import mirx.model as mm
+    m, sd = model_and_sd
+    x = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(77))
+    x[1] *= 30.0
+    x[2] *= 1e-3
+    with torch.no_grad():
+        assert m._h2_ok(x.cuda())
+        e2 = m(x.cuda()).cpu()
+        mm.SPLIT2H_DENSENET = False
+        try:
+            e3 = m(x.cuda()).cpu()
+        finally:
+            mm.SPLIT2H_DENSENET = True
+        ref = OD.embed(x, sd)
+    assert float((e2 - ref).abs().max()) <= 1e-5
+    assert float((e2 - e3).abs().max()) <= 2e-6
+    with torch.no_grad():
+        solo = m(x[2:3].cuda()).cpu()                   # alone, the small image gets a much finer scale
+    assert float((solo - e2[2:3]).abs().max()) <= 2e-6

@@ -22,10 +22,18 @@ def main():
     ap.add_argument("--no-hip-conv1x1", action="store_true")
     ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2", "dinov2", "medsiglip"])
     ap.add_argument("--no-split3-linear", action="store_true")
+    ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
+    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (direct2h | wino)")
     a = ap.parse_args()
     if a.no_split3_linear:
         import mirx.model as mm
         mm.SPLIT3_LINEAR = False
+    import mirx.model as mm
+    if a.no_split2h:
+        mm.SPLIT2H_DENSENET = False
+    if a.conv3x3:
+        for side_, kind_ in zip((56, 28, 14), a.conv3x3.split(',')):
+            mm.CONV3X3_KERNEL_H2[side_] = kind_
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     if a.model == "convnextv2":
