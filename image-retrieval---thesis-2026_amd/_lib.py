@@ -66,6 +66,9 @@ SYMBOLS = {
     "mirx_stem_conv7_bn_relu_pool_split3_into": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp]),
     "mirx_conv3x3_winograd_nchw_ranged": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp]),
     "mirx_conv3x3_direct_split2h_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "mirx_layernorm": (_int, [_vp, _i64, _int, _vp, _vp, ctypes.c_float, _vp, _int, _vp]),
+    "mirx_patchify_nchw": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, ctypes.c_float, _vp, _int, _vp]),
+    "mirx_attention_small": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),

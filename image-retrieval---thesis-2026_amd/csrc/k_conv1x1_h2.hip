@@ -149,9 +149,13 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
     auto stage = [&](int kt, int cur, float (&rnext)[8], float (&scn)[8], float (&shn)[8], const float (&rstore)[8],
                      const float (&scs)[8], const float (&shs)[8]) {
-        // stage kt visible: this wave's weight DMA of stage kt has landed (the two DMA pieces are OLDER than the 8
-        // activation loads of stage kt + 1 issued behind them, which stay in flight: vmcnt(8)); buffer cur ^ 1 free
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // stage kt visible: this wave's weight DMA of stage kt has landed.  vmcnt(0), NOT a counted wait: the two DMA
+        // pieces are older than the 8 activation loads issued behind them, and `vmcnt(8)` was tried to keep those loads
+        // in flight across the barrier -- it produced state-dependent results (embeddings off by 2e-5 once the caches
+        // were warm: the LDS-DMA pieces were still landing when the count had already dropped to 8), i.e. LDS-DMA and
+        // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
+        // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                     if (col >= n) continue;                     // zero-padded weight rows of the last output tile
                     float v = acc[mi][ni][r] * out_scale + (bias ? bias[col] : 0.f);
                     if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 2) v = gelu_tanh(v);
                     const int64_t idx = base + (int64_t)col * tpi;
                     if (RES) v = res[idx] + v;
                     y[idx] = v;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 if (row >= m) continue;
                 float v = acc[mi][ni][r] * out_scale + bv;
                 if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 2) v = gelu_tanh(v);
                 if (RES) v = res[row * n + col] + gv * v;
                 y[row * n + col] = v;
             }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
                             const float *res, const float *gamma, float x_scale, float out_scale, float *y, hipStream_t st) {
     if (m <= 0) return hipSuccess;
-    if (k % KC || n < 1 || act < 0 || act > 1) return hipErrorInvalidValue;
+    if (k % KC || n < 1 || act < 0 || act > 2) return hipErrorInvalidValue;
     const int ntn = (n + TN - 1) / TN;                 // w2 holds ntn * 128 rows, zero beyond n
     const int64_t total = ((m + TM - 1) / TM) * ntn;
     const int64_t per_xcd = (total + 7) / 8;
@@ -248,9 +250,10 @@ hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2
                            gamma, y, ntn, total, per_xcd, 0, x_scale, out_scale);                          \
     }
     if (res) {
+        if (act == 2) return hipErrorInvalidValue;
         if (act) MIRX_H2(1, true) else MIRX_H2(0, true)
     } else {
-        if (act) MIRX_H2(1, false) else MIRX_H2(0, false)
+        if (act == 2) MIRX_H2(2, false) else if (act) MIRX_H2(1, false) else MIRX_H2(0, false)
     }
 #undef MIRX_H2
     return hipGetLastError();

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
                     if (col >= n) continue;                     // zero-padded weight rows of the last output tile
                     float v = acc[mi][ni][r] + (bias ? bias[col] : 0.f);
                     if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 2) v = gelu_tanh(v);
                     const int64_t idx = base + (int64_t)col * tpi;
                     if (RES) v = res[idx] + v;
                     y[idx] = v;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
                 if (row >= m) continue;
                 float v = acc[mi][ni][r] + bv;
                 if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 2) v = gelu_tanh(v);
                 if (RES) v = res[row * n + col] + gv * v;
                 y[row * n + col] = v;
             }
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_s3(const float *__restrict__ 
 hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3, const float *bias, int n, int act,
                             const float *res, const float *gamma, float *y, int tokens_per_image, hipStream_t st) {
     if (m <= 0) return hipSuccess;
-    if (k % KC || n < 1 || act < 0 || act > 1 || tokens_per_image < 0) return hipErrorInvalidValue;
+    if (k % KC || n < 1 || act < 0 || act > 2 || tokens_per_image < 0) return hipErrorInvalidValue;
     const int ntn = (n + TN - 1) / TN;                 // w3 holds ntn * 128 rows, zero beyond n
     const int64_t total = ((m + TM - 1) / TM) * ntn;
     const int64_t per_xcd = (total + 7) / 8;
@@ -272,9 +274,10 @@ hipError_t launch_linear_s3(const float *x, int64_t m, int k, const uint16_t *w3
             if (res) MIRX_L3(0, true, true, false) else MIRX_L3(0, false, true, false)
         }
     } else if (res) {
+        if (act == 2) return hipErrorInvalidValue;
         if (act) MIRX_L3(1, true, false, false) else MIRX_L3(0, true, false, false)
     } else {
-        if (act) MIRX_L3(1, false, false, false) else MIRX_L3(0, false, false, false)
+        if (act == 2) MIRX_L3(2, false, false, false) else if (act) MIRX_L3(1, false, false, false) else MIRX_L3(0, false, false, false)
     }
 #undef MIRX_L3
     return hipGetLastError();

@@ -669,7 +669,7 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream) {
     MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split3: k must be a multiple of 16");
-    MIRX_CHECK(act == 0 || act == 1, "linear_split3: act is 0 (none) or 1 (gelu)");
+    MIRX_CHECK(act >= 0 && act <= 2 && !(act == 2 && residual_or_null), "linear_split3: act is 0 (none), 1 (erf gelu) or 2 (tanh gelu, no residual)");
     MIRX_CHECK(m == 0 || (x && w3 && y), "linear_split3: null buffer");
     MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split3: gamma scales the residual branch only");
     MIRX_CHECK(x != y, "linear_split3: y may alias the residual, not the input");
@@ -682,7 +682,7 @@ int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const 
                         const float *residual_or_null, const float *gamma_or_null, float x_scale, float out_scale,
                         float *y, void *stream) {
     MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split2h: k must be a multiple of 16");
-    MIRX_CHECK(act == 0 || act == 1, "linear_split2h: act is 0 (none) or 1 (gelu)");
+    MIRX_CHECK(act >= 0 && act <= 2 && !(act == 2 && residual_or_null), "linear_split2h: act is 0 (none), 1 (erf gelu) or 2 (tanh gelu, no residual)");
     MIRX_CHECK(m == 0 || (x && w2 && y), "linear_split2h: null buffer");
     MIRX_CHECK(residual_or_null || !gamma_or_null, "linear_split2h: gamma scales the residual branch only");
     MIRX_CHECK(x != y, "linear_split2h: y may alias the residual, not the input");
@@ -715,6 +715,44 @@ int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, 
     MIRX_CHECK(n >= 0 && hw >= 1 && c >= 4 && c % 4 == 0 && (n == 0 || (x && scale && shift)),
                "grn_apply: c must be a multiple of 4");
     MIRX_HIP(launch_grn_apply(x, n, hw, c, scale, shift, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
+                   float *y, int tokens_per_image, void *stream) {
+    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0, "layernorm: c must be a multiple of 4");
+    MIRX_CHECK(m == 0 || (x && y), "layernorm: null buffer");
+    MIRX_CHECK(tokens_per_image >= 0 && (tokens_per_image == 0 || (c <= 512 && x != y)),
+               "layernorm: the channels-first form needs c <= 512 and y != x");
+    MIRX_CHECK(eps >= 0.f, "layernorm: eps must be non-negative");
+    MIRX_HIP(launch_layernorm_rows(x, m, c, gamma_or_null, beta_or_null, eps, y, tokens_per_image,
+                                   reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_patchify_nchw(const float *x, int64_t n, int c, int h, int w, int patch, const float *ln_gamma_or_null,
+                       const float *ln_beta_or_null, float eps, float *out, int row_stride, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && c >= 1 && patch >= 1 && h >= patch && w >= patch, "patchify: bad geometry");
+    MIRX_CHECK(row_stride >= c * patch * patch, "patchify: row_stride smaller than c * patch * patch");
+    MIRX_CHECK((ln_gamma_or_null == nullptr) == (ln_beta_or_null == nullptr), "patchify: gamma and beta go together");
+    MIRX_CHECK(n == 0 || (x && out), "patchify: null buffer");
+    MIRX_CHECK((size_t)2 * patch * w * sizeof(float) <= 64 * 1024, "patchify: strip too wide for the LayerNorm2d prologue");
+    MIRX_HIP(launch_patchify(x, n, c, h, w, patch, ln_gamma_or_null, ln_beta_or_null, eps, out, row_stride,
+                             reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_attention_small(const float *q, int64_t q_row_stride, const float *k, const float *v, int64_t kv_row_stride,
+                         const uint8_t *key_mask_or_null, int64_t batch, int heads, int head_dim, int n_queries, int n_keys,
+                         float scale, float *out, void *stream) {
+    MIRX_CHECK(batch >= 0 && heads >= 1 && n_queries >= 0 && n_keys >= 1, "attention_small: bad sizes");
+    MIRX_CHECK(head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 72, "attention_small: head_dim 16 / 32 / 64 / 72");
+    MIRX_CHECK(q_row_stride >= (int64_t)heads * head_dim && kv_row_stride >= (int64_t)heads * head_dim &&
+                   q_row_stride % 4 == 0 && kv_row_stride % 4 == 0,
+               "attention_small: row strides must cover heads * head_dim and be multiples of 4");
+    MIRX_CHECK(batch == 0 || n_queries == 0 || (q && k && v && out), "attention_small: null buffer");
+    MIRX_HIP(launch_attention_small(q, q_row_stride, k, v, kv_row_stride, key_mask_or_null, batch, heads, head_dim,
+                                    n_queries, n_keys, scale, out, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

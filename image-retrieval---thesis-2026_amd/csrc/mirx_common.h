@@ -93,6 +93,12 @@ __device__ inline double lane_tree_score(const float *__restrict__ q, const floa
     acc = wave_butterfly_sum(acc);
     return METRIC == 0 ? acc : -acc;
 }
+// tanh-form GELU (transformers "gelu_pytorch_tanh", the SigLIP MLP activation): 0.5 v (1 + tanh(sqrt(2/pi) (v + 0.044715 v^3)))
+__device__ inline float gelu_tanh(float v) {
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    return 0.5f * v * (1.f + tanhf(u));
+}
+
 // ---- value ranges that travel with activations (two-fp16-term kernels) ---------------------------------
 // A producer publishes the largest |value| it wrote into one of RANGE_SLOTS floats (slot = workgroup % 64) with an
 // unsigned atomic max: the bit patterns of non-negative floats order like the floats, +inf and NaN sort above every

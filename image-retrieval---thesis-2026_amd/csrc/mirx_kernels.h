@@ -98,6 +98,15 @@ hipError_t launch_conv3x3_d3(const float *x, const uint16_t *w3, int64_t n, int 
 hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_range, float *out_range, hipStream_t st);
 
+// ---- k_norm.hip: LayerNorm over rows, patchify (+ LayerNorm2d), attention for short query sets ------------------
+hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
+                                 float *y, int tokens_per_image, hipStream_t st);
+hipError_t launch_patchify(const float *x, int64_t n, int c, int h, int w, int p, const float *gamma, const float *beta,
+                           float eps, float *out, int kpad, hipStream_t st);
+hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, const float *v, int64_t kv_rs,
+                                  const uint8_t *key_mask, int64_t batch, int heads, int head_dim, int nq, int nk,
+                                  float scale, float *out, hipStream_t st);
+
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                             hipStream_t st);

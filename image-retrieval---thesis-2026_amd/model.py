@@ -820,6 +820,7 @@ class DenseNet121(nn.Module):
                 nxt = torch.empty((b, blocks[k + 1][1].cout, side, side), dtype=torch.float32, device=dev)
                 _transition_h2(buf, h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
                 buf = nxt
+        self.__dict__["_mirx_last_ranges"] = ranges            # kept for diagnostics (tools/h2_state_probe.py)
         return buf
 
     def _head_fused(self, fmap, normalize):

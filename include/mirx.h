@@ -215,6 +215,33 @@ int mirx_conv3x3_direct_split2h_nchw(const float *x, const void *w2, const float
                                      void *stream);
 
 /*
+ * Memory-bound glue of the token-major backbones, so that their forward runs without a library kernel:
+ *
+ * mirx_layernorm: y = (x - mean) / sqrt(var + eps) * gamma + beta over the last axis of x [m, c] (nn.LayerNorm inside
+ *   timm ConvNeXtV2 / ViT and transformers SigLIP: model.py:96-100, 459-463, 553-557); biased variance, fp32.
+ *   tokens_per_image == 0: y is [m, c] (may alias x); > 0: y is channels-first [m / tpi][c][tpi] (timm LayerNorm2d of the
+ *   ConvNeXt stem; c <= 512, y != x).  c % 4 == 0.
+ * mirx_patchify_nchw: non-overlapping patch x patch blocks of x [n, c, h, w] as rows
+ *   out[((b * (h/patch) + py) * (w/patch) + px) * row_stride + (ch * patch + ky) * patch + kx], columns beyond
+ *   c * patch * patch zeroed: a Conv2d(c, cout, kernel = stride = patch) is patchify + mirx_linear_split3 / _split2h with
+ *   weight.flatten(1) (the ViT / SigLIP patch embedding, the ConvNeXt stem and downsample convolutions).  With
+ *   ln_gamma / ln_beta every pixel is first normalised over its c channels (timm LayerNorm2d in front of the ConvNeXt
+ *   downsample conv).
+ * mirx_attention_small: softmax(scale q k^T) v for short query sets, one wavefront per (image, head, query), fp32:
+ *   q[(b * n_queries + i) * q_row_stride + hd * head_dim + d], k / v likewise with kv_row_stride, key_mask[b * n_keys + j]
+ *   != 0 keeps key j (NULL: all keys; a query whose keys are all masked gives zeros), out [batch, n_queries, heads *
+ *   head_dim].  Used for the SigLIP text tower (64 tokens, padding mask: eval_medsiglip.py:164-186) and the SigLIP
+ *   attention-pooling head (1 probe query).  head_dim 16 / 32 / 64 / 72.
+ */
+int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
+                   float *y, int tokens_per_image, void *stream);
+int mirx_patchify_nchw(const float *x, int64_t n, int c, int h, int w, int patch, const float *ln_gamma_or_null,
+                       const float *ln_beta_or_null, float eps, float *out, int row_stride, void *stream);
+int mirx_attention_small(const float *q, int64_t q_row_stride, const float *k, const float *v, int64_t kv_row_stride,
+                         const uint8_t *key_mask_or_null, int64_t batch, int heads, int head_dim, int n_queries, int n_keys,
+                         float scale, float *out, void *stream);
+
+/*
  * Linear layer of the token-major backbones (replaces the nn.Linear calls inside the timm / transformers
  * models the reference instantiates: model.py:448-494 DinoV2, model.py:87-118 ConvNeXtV2,
  * model.py:536-638 MedSigLIP vision tower), fp32-grade on the bf16 matrix pipe with three bf16 terms per operand:

@@ -84,6 +84,18 @@ def covidx_labels():
     return np.asarray(labs, dtype=np.int64)
 
 
+def base_ranking(emb, metric):
+    """A plain-numpy fp64 ranking (stable argsort, row per query, self last) that the reference's fp32 ranking is stored
+    RELATIVE to: tests rebuild the reference ranking as this + the stored patch (tests/_audit.py)."""
+    e = np.asarray(emb, dtype=np.float64)
+    if metric == "cosine":
+        s = e @ e.T
+    else:
+        s = -np.sqrt(np.maximum(((e[:, None, :] - e[None, :, :]) ** 2).sum(-1), 0.0))
+    np.fill_diagonal(s, -np.inf)
+    return np.argsort(-s, axis=1, kind="stable")
+
+
 def class_clustered_embeddings(labels, dim, seed, spread):
     """Unit-norm embeddings with class structure so that metrics are not trivially chance."""
     import torch
@@ -178,8 +190,12 @@ def main():
             rec[f"{metric}_aps"] = aps
             rec[f"{metric}_pr"] = pr
             rec[f"{metric}_prs"] = prs
-            if len(labels) <= 300:  # reference fp32 ranking (tie order unstable; report-only)
+            if len(labels) <= 300:  # reference fp32 ranking, stored whole
                 rec[f"{metric}_ranks_ref_fp32"] = ranks.astype(np.int16)
+            # ... and for every set as a patch against base_ranking(): rows (query, position, id the reference has there)
+            base = base_ranking(emb.numpy(), metric)
+            qq, pp = np.nonzero(ranks.T != base)
+            rec[f"{metric}_refpatch"] = np.stack([qq, pp, ranks.T[qq, pp]], axis=1).astype(np.int32)
             for k, v in cls.items():
                 rec[f"{metric}_cls_k{k}"] = np.array(list(v.values()), dtype=np.float64)
         # fusion_eval metrics (string labels, self excluded by path)

@@ -50,42 +50,45 @@ def _rank(z, metric):
 @pytest.mark.parametrize("name", SETS)
 @pytest.mark.parametrize("metric", ["cdist", "cosine"])
 def test_tail_against_reference_outputs(golden_dir, name, metric):
-    """Two checks per golden set:
-    (1) metric functions alone: fed the reference's OWN fp32 ranking they must reproduce the
-        reference's outputs to 1e-12 (pins compute_map / retrieval_accuracy / majority vote);
-    (2) whole tail from the fp64 search oracle: the reference's fp32 cdist/argsort swaps
-        near-ties, so the comparison allows -- and prints -- those queries.
+    """Per golden set (SURVEY H2 / VERDICT r1 1c):
+    (1) metric functions alone: fed the reference's OWN fp32 ranking they reproduce the reference's outputs to 1e-12
+        (pins compute_map / retrieval_accuracy / majority vote);
+    (2) the fp64 search oracle against the reference's ranking: every position where they differ is audited -- the two
+        ids must be an fp32 near-tie (fp64 score gap < 1e-6); queries without such a swap reproduce the reference's
+        per-query AP / precision to 1e-12, and the aggregates can move only by what the swapped queries explain.
     """
+    from _audit import audit, reference_ranking
     z = np.load(os.path.join(golden_dir, f"tail_{name}.npz"))
     labels = z["labels"]
     n = len(labels)
-    if f"{metric}_ranks_ref_fp32" in z.files:
-        ref = z[f"{metric}_ranks_ref_fp32"].astype(np.int64)          # [db, nq] as the reference has it
-        mAP, aps, pr, prs = OM.compute_map(ref, labels, [1, 5, 10])
-        assert mAP == pytest.approx(float(z[f"{metric}_mAP"]), abs=1e-12)
-        np.testing.assert_allclose(aps, z[f"{metric}_aps"], atol=1e-12)
-        np.testing.assert_allclose(pr, z[f"{metric}_pr"], atol=1e-12)
-        np.testing.assert_allclose(prs, z[f"{metric}_prs"], atol=1e-12)
-        np.testing.assert_allclose(OM.retrieval_accuracy(ref.T[:, :10], labels, (1, 5, 10)),
-                                   z[f"{metric}_acc"], atol=1e-5)
-        cls = OM.compute_classification_metrics(labels, ref.T, (1, 5, 10, 15, 20))
-        for k in (1, 5, 10, 15, 20):
-            np.testing.assert_allclose(cls[k], z[f"{metric}_cls_k{k}"], atol=1e-9)
+    ref = reference_ranking(z, metric)                                # [nq, n]
+    mAP, aps, pr, prs = OM.compute_map(ref.T, labels, [1, 5, 10])
+    assert mAP == pytest.approx(float(z[f"{metric}_mAP"]), abs=1e-12)
+    np.testing.assert_allclose(aps, z[f"{metric}_aps"], atol=1e-12)
+    np.testing.assert_allclose(pr, z[f"{metric}_pr"], atol=1e-12)
+    np.testing.assert_allclose(prs, z[f"{metric}_prs"], atol=1e-12)
+    np.testing.assert_allclose(OM.retrieval_accuracy(ref[:, :10], labels, (1, 5, 10)), z[f"{metric}_acc"], atol=1e-5)
+    cls = OM.compute_classification_metrics(labels, ref, (1, 5, 10, 15, 20))
+    for k in (1, 5, 10, 15, 20):
+        np.testing.assert_allclose(cls[k], z[f"{metric}_cls_k{k}"], atol=1e-9)
 
     ranks = _rank(z, metric)                       # [nq, n], fp64 scores, ties -> lowest id
-    flips = 0
-    if f"{metric}_ranks_ref_fp32" in z.files:
-        flips = int(np.sum(np.any(ref.T[:, :20] != ranks[:, :20], axis=1)))
-        print(f"{name}/{metric}: reference fp32 top-20 order differs from the fp64 oracle on "
-              f"{flips}/{n} queries (fp32 near-ties)")
-        assert flips <= max(2, n // 50)
-    slack = max(flips, n // 100) + 1               # queries that may move by one rank
-    mAP, aps, pr, prs = OM.compute_map(ranks.T, labels, [1, 5, 10])
-    assert abs(mAP - float(z[f"{metric}_mAP"])) <= slack / n * 0.05 + 1e-9
-    assert np.all(np.abs(pr - z[f"{metric}_pr"]) <= slack / n + 1e-9)
-    acc = OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10))
-    assert np.all(np.abs(np.asarray(acc) - z[f"{metric}_acc"]) <= 100.0 * slack / n + 1e-4)
-    assert np.count_nonzero(np.abs(aps - z[f"{metric}_aps"]) > 1e-9) <= slack * 4
+    flipped = audit(ranks, ref, z["embeds"], metric)
+    print(f"{name}/{metric}: the reference's fp32 ranking swaps near-ties (fp64 gap < 1e-6) in {len(flipped)}/{n} "
+          f"queries: {flipped.tolist()[:12]}")
+    same = np.setdiff1d(np.arange(n), flipped)
+    o_map, o_aps, o_pr, o_prs = OM.compute_map(ranks.T, labels, [1, 5, 10])
+    np.testing.assert_allclose(o_aps[same], z[f"{metric}_aps"][same], atol=1e-12)
+    np.testing.assert_allclose(o_prs[same], z[f"{metric}_prs"][same], atol=1e-12)
+    # aggregates: exactly the reference's value plus what the audited queries contribute
+    assert o_map == pytest.approx(float(z[f"{metric}_mAP"]) + float(np.sum(o_aps[flipped] - z[f"{metric}_aps"][flipped])) / n,
+                                  abs=1e-12)
+    np.testing.assert_allclose(o_pr, z[f"{metric}_pr"] + np.sum(o_prs[flipped] - z[f"{metric}_prs"][flipped], axis=0) / n,
+                               atol=1e-12)
+    if len(flipped) == 0:
+        assert o_map == pytest.approx(float(z[f"{metric}_mAP"]), abs=1e-12)          # tighter than the 1e-5 bar
+    acc = np.asarray(OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10)))
+    assert np.all(np.abs(acc - z[f"{metric}_acc"]) <= 100.0 * len(flipped) / n + 1e-4)
 
 
 @pytest.mark.parametrize("name", SETS)
@@ -125,15 +128,28 @@ def test_fuse(golden_dir):
 
 
 def test_evaluate_npz_fields(golden_dir):
-    """The .npz the reference's evaluate() writes (test.py:1122-1126): field inventory + values."""
+    """The .npz the reference's evaluate() writes (test.py:1122-1126): field inventory + values; the oracle's ranking
+    differs from the reference's only inside audited fp32 near-ties."""
+    from _audit import audit, reference_ranking
     z = np.load(os.path.join(golden_dir, "evaluate_covidx300_d64.npz"))
     need = {"embeds", "labels", "dists", "kappas", "acc", "mAP", "pr", "classification_k_values"} | {
         f"classification_k{k}" for k in (1, 5, 10, 15, 20)}
     assert need <= set(z.files)
     emb, labels = z["embeds"], z["labels"]
-    ranks = OS.rank_all(emb, emb, metric=OS.METRIC_NEG_L2, exclude=np.arange(len(emb)))
-    mAP, _, pr, _ = OM.compute_map(ranks.T, labels, [1, 5, 10])
-    assert mAP == pytest.approx(float(z["mAP"]), abs=2e-4)         # fp32 near-tie flips, see above
-    np.testing.assert_allclose(pr, z["pr"], atol=4 / 300)
-    np.testing.assert_allclose(OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10)), z["acc"], atol=1.0)
+    n = len(labels)
+    tail = np.load(os.path.join(golden_dir, "tail_covidx300_d64.npz"))     # same embeddings: holds the reference ranking
+    np.testing.assert_array_equal(tail["embeds"], emb)
+    ref = reference_ranking(tail, "cdist")
+    ranks = OS.rank_all(emb, emb, metric=OS.METRIC_NEG_L2, exclude=np.arange(n))
+    flipped = audit(ranks, ref, emb, "cdist")
+    mAP, aps, pr, prs = OM.compute_map(ranks.T, labels, [1, 5, 10])
+    r_map, r_aps, r_pr, r_prs = OM.compute_map(ref.T, labels, [1, 5, 10])
+    assert r_map == pytest.approx(float(z["mAP"]), abs=1e-12)               # swapped back: the reference's number
+    np.testing.assert_allclose(r_pr, z["pr"], atol=1e-12)
+    same = np.setdiff1d(np.arange(n), flipped)
+    np.testing.assert_allclose(aps[same], r_aps[same], atol=1e-12)
+    assert mAP == pytest.approx(float(z["mAP"]) + float(np.sum(aps[flipped] - r_aps[flipped])) / n, abs=1e-12)
+    np.testing.assert_allclose(OM.retrieval_accuracy(ref[:, :10], labels, (1, 5, 10)), z["acc"], atol=1e-5)
+    acc = np.asarray(OM.retrieval_accuracy(ranks[:, :10], labels, (1, 5, 10)))
+    assert np.all(np.abs(acc - z["acc"]) <= 100.0 * len(flipped) / n + 1e-4)
     assert np.all(np.isposinf(np.diag(z["dists"])))          # dists saved as +L2 with +inf diagonal
