@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .index import FlatIndex
-from .metrics import compute_classification_metrics, compute_map, retrieval_accuracy
+from .metrics import compute_classification_metrics, compute_map, compute_map_multilabel, retrieval_accuracy
 
 
 @torch.no_grad()
@@ -93,3 +93,41 @@ def evaluate(model, loader, device, args):
                  classification_k_values=list(classification_results.keys()),
                  **{f"classification_k{k}": np.array(list(v.values())) for k, v in classification_results.items()})
     return result
+
+
+@torch.no_grad()
+def evaluate_multilabels(model, loader, device, args):
+    """test.py:987-1062 (VinDr-CXR style multi-hot labels): embed loop -> cosine similarities with the diagonal excluded
+    -> mAP at Jaccard > 0.25 and > 0.5 (compute_map_multilabel) -> Precision@K (share of the top K with at least one label
+    in common with the query) and Recall@K (1 if any of the top K shares a label) for K in 1, 5, 10, 15, 20 -> optional
+    np.savez(embeds, labels).  Same prints; returns the numbers (the reference returns None).  The N x N matrix, its
+    two argsorts and the Python double loop are replaced by one resident index, one exact full ranking and tensor ops on
+    the device."""
+    embeds, labels = embed_loader(model, loader, device)
+    embeds_norm = torch.nn.functional.normalize(embeds.float(), p=2, dim=1)
+    ranks, _ = rank_self(embeds_norm, "cosine")                       # [N, N] row per query, self last
+    print("\n--- VinDr-CXR Retrieval Results ---")
+    out = {"mAP": {}, "precision": {}, "recall": {}}
+    for t in [0.25, 0.5]:
+        m = compute_map_multilabel(None, labels, threshold=t, ranks=ranks.t())
+        out["mAP"][t] = float(m)
+        print(f">> mAP (Jaccard > {t}): {m * 100.0:.2f}%")
+    k_values = [1, 5, 10, 15, 20]
+    lab = labels.to(ranks.device).float()
+    top = ranks[:, :max(k_values)]
+    matches = (lab[top] * lab[:, None, :]).sum(dim=2) > 0              # [N, maxk]: shares a label with the query
+    print(f'\n{"K":<5} | {"Precision@K":<15} | {"Recall@K":<15}')
+    print("-" * 40)
+    n = lab.shape[0]
+    for k in k_values:
+        cnt = matches[:, :k].sum(dim=1)
+        avg_precision = float((cnt.double() / k).sum() / n * 100)
+        avg_recall = float((cnt > 0).double().sum() / n * 100)
+        out["precision"][k], out["recall"][k] = avg_precision, avg_recall
+        print(f"{k:<5} | {avg_precision:<15.2f}% | {avg_recall:<15.2f}%")
+    if getattr(args, "save_dir", None):
+        os.makedirs(args.save_dir, exist_ok=True)
+        save_path = os.path.join(args.save_dir, "evaluation_results.npz")
+        np.savez(save_path, embeds=embeds.cpu().numpy(), labels=labels.cpu().numpy())
+        print(f"\n>> Results saved to {save_path}")
+    return out

@@ -5,7 +5,9 @@ Mirrors (paths into /root/reference):
   build_embedding_source, align_embedding_sources          fusion_eval/align.py:16-230
   ExperimentResult, run_late_fusion_experiments, normalize_similarity_matrix,
   confidence_based_fusion, top12_margin                     fusion_eval/evaluate.py:19-214
-  load_query_set                                            retrieval_analysis/comparison.py:41-84
+  load_query_set                                            retrieval_analysis/comparison.py:41-84 (mirx.adapter)
+The host half is written against the FORMAT (dump files, record fields, error conditions), column-wise: a source is a
+table (paths, labels, one matrix), alignment is two dictionaries and two gathers.
 
 MI355X design.  Every score-level fusion the reference evaluates is, per query q,
     fused[q, g] = wa_q * (a_q . a_g) + wb_q * (b_q . b_g) + const_q
@@ -19,11 +21,10 @@ resident rows, min / max / top-2 are k = 1..2 searches.  const_q does not change
 Scores are exact fp64 where the reference rounds its similarity matrices to fp32, so rankings can
 differ inside fp32 near-ties (tests state the tolerance).
 """
-import csv
 import json
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence
+from typing import Any, Dict, List, Mapping, Optional
 
 import numpy as np
 import torch
@@ -33,7 +34,7 @@ from .index import FlatIndex
 from .metrics import concat_fusion, l2_normalize, weighted_sum_fusion
 
 
-# ---- fusion_eval/align.py:16-41 ---------------------------------------------------------------
+# ---- public record types (field names are the contract: fusion_eval/align.py:16-41, evaluate.py:19-27) ---------------
 @dataclass(frozen=True)
 class EmbeddingRecord:
     image_path: str
@@ -61,205 +62,226 @@ class ExperimentResult:
     skipped_reason: Optional[str] = None
 
 
+# ---- embedding sources: columnar (paths, labels, one [N, D] matrix), never one Python object per row -----------------
+@dataclass
+class _Table:
+    """One embedding set as columns.  `raw` holds the per-row source dicts when the format has them (.json)."""
+    name: str
+    paths: List[str]
+    labels: List[Optional[str]]
+    matrix: np.ndarray                      # float32 [N, D]
+    raw: Optional[List[Mapping[str, Any]]] = None
+
+    def records(self):
+        raw = self.raw or [{}] * len(self.paths)
+        return [EmbeddingRecord(image_path=p, label=l, embedding=self.matrix[i], source_name=self.name, raw=raw[i])
+                for i, (p, l) in enumerate(zip(self.paths, self.labels))]
+
+    def row_of(self):
+        """image_path -> row; a path that occurs twice is an error (the alignment key must be unique)."""
+        index = {}
+        for i, p in enumerate(self.paths):
+            if index.setdefault(p, i) != i:
+                raise ValueError(f"{self.name}: image_path {p!r} occurs more than once")
+        return index
+
+
 class EmbeddingSource:
-    def fetch_all(self) -> List[EmbeddingRecord]:
+    """fetch_all() -> list[EmbeddingRecord] (the reference's interface); table() -> the same data as columns."""
+
+    def table(self) -> _Table:
         raise NotImplementedError
 
+    def fetch_all(self) -> List[EmbeddingRecord]:
+        return self.table().records()
 
-# ---- fusion_eval/align.py:96-140 --------------------------------------------------------------
+
+def _read_embedding_file(path: Path, name: str) -> _Table:
+    """The two dump formats of the reference (fusion_eval/align.py:96-140):
+    .npz  arrays `image_paths` [N], `embeddings` [N, D], optional `labels` [N];
+    .json {"records": [{"image_path", "label"?, "embedding": [...]}, ...]} or the bare list."""
+    kind = path.suffix.lower()
+    if kind == ".npz":
+        with np.load(path, allow_pickle=True) as z:
+            paths = [str(p) for p in z["image_paths"].tolist()]
+            labels = z["labels"].tolist() if "labels" in z.files else [None] * len(paths)
+            matrix = np.asarray(z["embeddings"], dtype=np.float32)
+        return _Table(name, paths, labels, matrix.reshape(len(paths), -1))
+    if kind == ".json":
+        with path.open("r", encoding="utf-8") as fh:
+            doc = json.load(fh)
+        rows = doc["records"] if isinstance(doc, dict) and "records" in doc else doc
+        matrix = np.asarray([r["embedding"] for r in rows], dtype=np.float32)
+        return _Table(name, [r["image_path"] for r in rows], [r.get("label") for r in rows],
+                      matrix.reshape(len(rows), -1), raw=list(rows))
+    raise ValueError(f"{path}: embedding dumps are .npz or .json")
+
+
 class FileEmbeddingSource(EmbeddingSource):
-    """.json ({"records": [{image_path, label, embedding}]} or a bare list) / .npz
-    ({image_paths, labels, embeddings})."""
-
     def __init__(self, path, source_name):
         self.path = Path(path)
         self.source_name = source_name
 
-    def fetch_all(self):
-        suffix = self.path.suffix.lower()
-        if suffix == ".json":
-            with self.path.open("r", encoding="utf-8") as handle:
-                data = json.load(handle)
-            rows = data.get("records", data) if isinstance(data, dict) else data
-            return [EmbeddingRecord(image_path=row["image_path"], label=row.get("label"),
-                                    embedding=np.asarray(row["embedding"], dtype=np.float32),
-                                    source_name=self.source_name, raw=row) for row in rows]
-        if suffix == ".npz":
-            payload = np.load(self.path, allow_pickle=True)
-            image_paths = payload["image_paths"].tolist()
-            labels = payload["labels"].tolist() if "labels" in payload else [None] * len(image_paths)
-            return [EmbeddingRecord(image_path=p, label=l, embedding=np.asarray(e, dtype=np.float32),
-                                    source_name=self.source_name, raw={})
-                    for p, l, e in zip(image_paths, labels, payload["embeddings"])]
-        raise ValueError(f"Unsupported embedding file format: {self.path}")
+    def table(self):
+        return _read_embedding_file(self.path, self.source_name)
 
 
 class CollectionEmbeddingSource(EmbeddingSource):
-    """The reference's MilvusEmbeddingSource (align.py:44-93) over a mirx.retriever.Collection:
-    all rows of the resident index with their host-side metadata."""
+    """The reference's MilvusEmbeddingSource (align.py:44-93) over a mirx.retriever.Collection: every row of the
+    resident index (ONE device read) with its host-side metadata."""
 
     def __init__(self, collection, name=None):
         self.collection = collection
         self.name = name or collection.name
 
-    def fetch_all(self):
+    def table(self):
         n = self.collection.num_entities
-        if n == 0:
-            return []
-        rows, _ = self.collection.index.rows(0, n)
-        rows = rows.cpu().numpy()
         meta = self.collection._meta
-        return [EmbeddingRecord(image_path=meta["image_path"][i], label=meta["label"][i], embedding=rows[i],
-                                source_name=self.name, raw={"id": i}) for i in range(n)
-                if meta["image_path"][i] is not None]
+        if n == 0:
+            return _Table(self.name, [], [], np.zeros((0, self.collection.dim), np.float32))
+        rows = self.collection.index.rows(0, n)[0].cpu().numpy()
+        keep = [i for i in range(n) if meta["image_path"][i] is not None]
+        labels = meta.get("label", [None] * n)
+        return _Table(self.name, [meta["image_path"][i] for i in keep], [labels[i] for i in keep], rows[keep],
+                      raw=[{"id": i} for i in keep])
 
 
 MilvusEmbeddingSource = CollectionEmbeddingSource
 
 
 def build_embedding_source(config):
-    """align.py:143-152.  {"type": "file", "path", "name"} or {"type": "collection"|"milvus",
-    "collection": <mirx.retriever.Collection>, "name"} (there is no server to connect to)."""
-    source_type = config.get("type", "milvus")
-    if source_type == "file":
-        return FileEmbeddingSource(path=config["path"], source_name=config["name"])
-    if source_type in ("milvus", "collection"):
-        if "collection" not in config:
+    """{"type": "file", "path", "name"} or {"type": "collection" | "milvus", "collection": <Collection>, "name"}.
+    There is no server to dial: a milvus-typed source must hand over the resident Collection."""
+    kind = config.get("type", "milvus")
+    if kind == "file":
+        return FileEmbeddingSource(config["path"], config["name"])
+    if kind in ("milvus", "collection"):
+        if config.get("collection") is None:
             raise ValueError("in-process build: pass the resident Collection as config['collection']")
         return CollectionEmbeddingSource(config["collection"], config.get("name"))
-    raise ValueError(f"Unsupported source type: {source_type}")
+    raise ValueError(f"unknown embedding source type {kind!r} (file | collection | milvus)")
 
 
 def save_embedding_file(path, image_paths, labels, embeddings):
-    """Write a gallery in the reference's FileEmbeddingSource formats (.npz or .json)."""
+    """Write a gallery in either dump format, readable by the reference's FileEmbeddingSource."""
     path = Path(path)
-    emb = embeddings.detach().cpu().numpy() if torch.is_tensor(embeddings) else np.asarray(embeddings)
-    emb = emb.astype(np.float32)
-    if not (len(image_paths) == len(labels) == emb.shape[0]):
-        raise ValueError("column lengths differ")
-    if path.suffix.lower() == ".npz":
-        np.savez(path, image_paths=np.array([str(p) for p in image_paths]), labels=np.array(list(labels)),
-                 embeddings=emb)
-    elif path.suffix.lower() == ".json":
-        with path.open("w", encoding="utf-8") as handle:
-            json.dump({"records": [{"image_path": str(p), "label": l, "embedding": [float(v) for v in e]}
-                                   for p, l, e in zip(image_paths, labels, emb)]}, handle)
+    matrix = (embeddings.detach().cpu().numpy() if torch.is_tensor(embeddings) else np.asarray(embeddings)).astype(np.float32)
+    paths = [str(p) for p in image_paths]
+    labels = list(labels)
+    if not (len(paths) == len(labels) == matrix.shape[0]):
+        raise ValueError("image_paths, labels and embeddings must have one entry per row")
+    kind = path.suffix.lower()
+    if kind == ".npz":
+        np.savez(path, image_paths=np.array(paths), labels=np.array(labels), embeddings=matrix)
+    elif kind == ".json":
+        doc = {"records": [{"image_path": p, "label": l, "embedding": row.tolist()} for p, l, row in zip(paths, labels, matrix)]}
+        with path.open("w", encoding="utf-8") as fh:
+            json.dump(doc, fh)
     else:
-        raise ValueError(f"Unsupported embedding file format: {path}")
+        raise ValueError(f"{path}: embedding dumps are .npz or .json")
 
 
 def ingest_embedding_file(collection, path, batch_size=65536):
-    """Load an embedding dump straight into a resident Collection (the insert loop of
-    ingest_embeddings.py:399-411 without the model).  Returns the number of rows inserted."""
-    records = FileEmbeddingSource(path, collection.name).fetch_all()
-    for s in range(0, len(records), batch_size):
-        chunk = records[s:s + batch_size]
-        collection.insert([[r.image_path for r in chunk], [r.label for r in chunk],
-                           np.stack([r.embedding for r in chunk])])
+    """Load an embedding dump straight into a resident Collection (the insert loop of ingest_embeddings.py:399-411
+    without the model): whole column slices per insert.  Returns the number of rows inserted."""
+    t = _read_embedding_file(Path(path), collection.name)
+    for s in range(0, len(t.paths), batch_size):
+        collection.insert([t.paths[s:s + batch_size], t.labels[s:s + batch_size], t.matrix[s:s + batch_size]])
     collection.flush()
-    return len(records)
+    return len(t.paths)
 
 
-# ---- retrieval_analysis/comparison.py:41-84 (paths only) ---------------------------------------
 def load_query_set(path):
-    path = Path(path)
-    suffix = path.suffix.lower()
-    if suffix == ".json":
-        with path.open("r", encoding="utf-8") as handle:
-            data = json.load(handle)
-        if isinstance(data, dict):
-            data = data.get("queries", data.get("results", []))
-        return [item.get("image_path", item.get("query_image_path")) for item in data
-                if item.get("image_path", item.get("query_image_path"))]
-    if suffix == ".csv":
-        with path.open("r", encoding="utf-8", newline="") as handle:
-            return [row.get("image_path") or row.get("query_image_path") for row in csv.DictReader(handle)
-                    if row.get("image_path") or row.get("query_image_path")]
-    out = []
-    with path.open("r", encoding="utf-8") as handle:
-        for line in handle:
-            s = line.strip()
-            if s and not s.startswith("#"):
-                out.append(s.split()[0])
-    return out
+    """Paths of an ordered query set (.json / .csv / text; retrieval_analysis/comparison.py:41-84).  The records with
+    their labels: mirx.adapter.load_query_set."""
+    from .adapter import load_query_set as _records
+    return [q.image_path for q in _records(path)]
 
 
-# ---- fusion_eval/align.py:155-230 --------------------------------------------------------------
-def _index_records(records: Iterable[EmbeddingRecord], source_name):
-    indexed = {}
-    for record in records:
-        if record.image_path in indexed:
-            raise ValueError(f"Duplicate image_path found in {source_name}: {record.image_path}")
-        indexed[record.image_path] = record
-    return indexed
+def _table_of(source):
+    if isinstance(source, EmbeddingSource) and type(source).table is not EmbeddingSource.table:
+        return source.table()
+    recs = source.fetch_all()                              # foreign sources that only implement fetch_all()
+    name = recs[0].source_name if recs else "source"
+    dim = recs[0].embedding.shape[-1] if recs else 0
+    return _Table(name, [r.image_path for r in recs], [r.label for r in recs],
+                  np.stack([r.embedding for r in recs]).astype(np.float32) if recs else np.zeros((0, dim), np.float32))
 
 
 def align_embedding_sources(conv_source, dino_source, query_set_path=None, strict_label_check=True):
-    conv_records = _index_records(conv_source.fetch_all(), "ConvNeXt")
-    dino_records = _index_records(dino_source.fetch_all(), "DINO")
-    conv_paths, dino_paths = set(conv_records), set(dino_records)
-    coverage = {"present_in_conv_only": sorted(conv_paths - dino_paths),
-                "present_in_dino_only": sorted(dino_paths - conv_paths),
-                "present_in_both": sorted(conv_paths & dino_paths)}
-    if query_set_path:
-        target_paths = [p for p in load_query_set(query_set_path) if p in conv_paths and p in dino_paths]
-    else:
-        target_paths = coverage["present_in_both"]
-    labels, conv_emb, dino_emb, final_paths = [], [], [], []
-    for image_path in target_paths:
-        c, d = conv_records[image_path], dino_records[image_path]
-        if strict_label_check and c.label != d.label:
-            raise ValueError(f"Label mismatch for image_path={image_path}: conv={c.label!r}, dino={d.label!r}")
-        final_paths.append(image_path)
-        labels.append(c.label or d.label or "unknown")
-        conv_emb.append(c.embedding)
-        dino_emb.append(d.embedding)
-    if not final_paths:
-        raise ValueError("No aligned samples found across the requested sources")
-    return AlignedEmbeddings(image_paths=final_paths, labels=labels,
-                             conv_embeddings=np.stack(conv_emb).astype(np.float32),
-                             dino_embeddings=np.stack(dino_emb).astype(np.float32), coverage=coverage)
+    """Rows of the two sources matched by image_path (fusion_eval/align.py:155-230): `coverage` lists what each side
+    has; the aligned set is the sorted intersection, or the query set's order restricted to it; a label that differs
+    between the sides raises unless strict_label_check is off (then the ConvNeXt side's label wins); an empty result
+    raises.  Done with two dictionaries and two fancy-indexed gathers."""
+    conv, dino = _table_of(conv_source), _table_of(dino_source)
+    conv.name, dino.name = "ConvNeXt", "DINO"
+    ci, di = conv.row_of(), dino.row_of()
+    both = sorted(ci.keys() & di.keys())
+    coverage = {"present_in_conv_only": sorted(ci.keys() - di.keys()),
+                "present_in_dino_only": sorted(di.keys() - ci.keys()), "present_in_both": both}
+    order = both if not query_set_path else [p for p in load_query_set(query_set_path) if p in ci and p in di]
+    if not order:
+        raise ValueError("the two sources share no image_path (after the query-set filter): nothing to fuse")
+    crow = np.fromiter((ci[p] for p in order), dtype=np.int64, count=len(order))
+    drow = np.fromiter((di[p] for p in order), dtype=np.int64, count=len(order))
+    labels = []
+    for p, i, j in zip(order, crow, drow):
+        lc, ld = conv.labels[i], dino.labels[j]
+        if strict_label_check and lc != ld:
+            raise ValueError(f"{p}: the sources disagree on the label ({lc!r} vs {ld!r})")
+        labels.append(lc or ld or "unknown")
+    return AlignedEmbeddings(image_paths=order, labels=labels, conv_embeddings=conv.matrix[crow].astype(np.float32),
+                             dino_embeddings=dino.matrix[drow].astype(np.float32), coverage=coverage)
 
 
-# ---- fusion_eval/evaluate.py:150-214: matrix-level helpers (host, for callers that hold matrices) ----
-def normalize_similarity_matrix(similarity, mode="none"):
-    if mode == "none":
-        return similarity.astype(np.float32, copy=True)
-    similarity = similarity.astype(np.float32, copy=True)
-    diag = np.diag(similarity).copy()
+# ---- matrix-level score fusion (for callers that already hold similarity matrices; the resident-index path below does
+# not build them).  Arithmetic is fp32 in the reference's operation order (fusion_eval/evaluate.py:152-214): tests compare
+# bit for bit with its outputs. -----------------------------------------------------------------------------------------
+def _row_affine(sim, mode):
+    """(offset, scale) per row such that normalised = (sim - offset) / scale."""
     if mode == "zscore":
-        stds = np.maximum(np.std(similarity, axis=1, keepdims=True), 1e-12)
-        normalized = (similarity - np.mean(similarity, axis=1, keepdims=True)) / stds
-    elif mode == "minmax":
-        mins = np.min(similarity, axis=1, keepdims=True)
-        scales = np.maximum(np.max(similarity, axis=1, keepdims=True) - mins, 1e-12)
-        normalized = (similarity - mins) / scales
-    else:
-        raise ValueError(f"Unsupported score normalization mode: {mode}. Use one of: none, zscore, minmax")
-    np.fill_diagonal(normalized, diag)
-    return normalized
+        return np.mean(sim, axis=1, keepdims=True), np.maximum(np.std(sim, axis=1, keepdims=True), 1e-12)
+    if mode == "minmax":
+        lo = np.min(sim, axis=1, keepdims=True)
+        return lo, np.maximum(np.max(sim, axis=1, keepdims=True) - lo, 1e-12)
+    raise ValueError(f"score normalization {mode!r}: use one of none, zscore, minmax")
+
+
+def normalize_similarity_matrix(similarity, mode="none"):
+    """Row-wise z-score / min-max of a similarity matrix; the diagonal keeps its original values."""
+    sim = similarity.astype(np.float32, copy=True)
+    if mode == "none":
+        return sim
+    offset, scale = _row_affine(sim, mode)
+    out = (sim - offset) / scale
+    idx = np.arange(min(sim.shape))
+    out[idx, idx] = sim[idx, idx]
+    return out
 
 
 def top12_margin(similarity):
+    """Best minus second-best score of every row."""
     if similarity.shape[1] < 2:
-        raise ValueError("Need at least two gallery scores per query for confidence margin")
-    top2 = np.partition(similarity, kth=-2, axis=1)[:, -2:]
-    return np.max(top2, axis=1) - np.min(top2, axis=1)
+        raise ValueError("a confidence margin needs at least two gallery scores per query")
+    two = np.partition(similarity, kth=-2, axis=1)[:, -2:]
+    return np.max(two, axis=1) - np.min(two, axis=1)
 
 
 def confidence_based_fusion(conv_similarity, dino_similarity):
+    """alpha_q = margin_conv / (margin_conv + margin_dino + 1e-8) per query (self excluded), fused = alpha conv +
+    (1 - alpha) dino."""
     if conv_similarity.shape != dino_similarity.shape:
-        raise ValueError("Conv and DINO similarity matrices must have the same shape")
-    conv_scores = conv_similarity.astype(np.float32, copy=True)
-    dino_scores = dino_similarity.astype(np.float32, copy=True)
-    np.fill_diagonal(conv_scores, -np.inf)
-    np.fill_diagonal(dino_scores, -np.inf)
-    conv_conf, dino_conf = top12_margin(conv_scores), top12_margin(dino_scores)
-    alpha = conv_conf / (conv_conf + dino_conf + 1e-8)
-    fused = alpha[:, None] * conv_scores + (1.0 - alpha[:, None]) * dino_scores
-    return {"similarity": fused, "conv_selected_queries": int(np.sum(alpha >= 0.5)),
-            "dino_selected_queries": int(np.sum(alpha < 0.5)), "alpha_mean": float(np.mean(alpha)),
-            "alpha_std": float(np.std(alpha))}
+        raise ValueError("the two similarity matrices differ in shape")
+    mats = []
+    for m in (conv_similarity, dino_similarity):
+        m = m.astype(np.float32, copy=True)
+        np.fill_diagonal(m, -np.inf)
+        mats.append(m)
+    mc, md = top12_margin(mats[0]), top12_margin(mats[1])
+    alpha = mc / (mc + md + 1e-8)
+    return {"similarity": alpha[:, None] * mats[0] + (1.0 - alpha[:, None]) * mats[1],
+            "conv_selected_queries": int(np.sum(alpha >= 0.5)), "dino_selected_queries": int(np.sum(alpha < 0.5)),
+            "alpha_mean": float(np.mean(alpha)), "alpha_std": float(np.std(alpha))}
 
 
 # ---- the device path -----------------------------------------------------------------------------
@@ -460,13 +482,4 @@ def text_rerank_evaluate(embeds, concept_image_embeds, text_embeds, labels, rera
 
 
 # ---- retrieval_analysis/rerank.py:10-26 ----------------------------------------------------------
-class Reranker:
-    """Hook of retrieval_analysis.compare_models: ``rerank(query, results) -> iterable of results``."""
-
-    def rerank(self, query, results):
-        raise NotImplementedError
-
-
-class IdentityReranker(Reranker):
-    def rerank(self, query, results):
-        return list(results)
+from .adapter import IdentityReranker, Reranker  # noqa: E402,F401  (retrieval_analysis/rerank.py:10-25)

@@ -1,0 +1,106 @@
+"""Zero-shot classification + all-pairs retrieval evaluation of a SigLIP-style dual encoder.
+
+Mirrors (paths into /root/reference):
+  COVIDX_LABEL_TO_TEXT                               train_medsiglip.py:21-25
+  get_text_features(model, processor, device, prompts, max_text_length)   eval_medsiglip.py:163-186
+  evaluate(model, processor, loader, device, args)                        eval_medsiglip.py:189-260
+Same stages and prints as the reference: class prompts -> unit-norm text features; per batch image features -> unit
+norm -> logits = exp(logit_scale) * img @ txt.T -> argmax; then accuracy / macro P / R / F1 of the zero-shot
+predictions and the retrieval tail (R@K, mAP, mP@K, majority-vote classification) over the cosine similarities of the
+image features with the diagonal excluded.  What changes underneath: the image features never leave the GPU, the
+N x N similarity matrix, its topk and its argsort are replaced by one resident FlatIndex and libmirx's exact full
+ranking (fp64 scores, ties -> lowest id), and AP / precision@k run over that ranking on the device.  `model` is anything
+with the transformers SiglipModel surface (mirx.siglip.SiglipDualEncoder, or the reference's own object); `processor`
+anything whose `.tokenizer(prompts, max_length=..., padding="max_length", truncation=True, return_attention_mask=True,
+return_tensors="pt")` returns input_ids / attention_mask.  Returns the numbers it prints (the reference returns None).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .evaluate import rank_self
+from .metrics import _prf, compute_classification_metrics, compute_map, retrieval_accuracy
+
+COVIDX_LABEL_TO_TEXT = {
+    0: "A chest X-ray showing no evidence of pneumonia or COVID-19 infection.",
+    1: "A chest X-ray showing findings consistent with pneumonia.",
+    2: "A chest X-ray showing findings consistent with COVID-19 pneumonia.",
+}
+
+
+def _features(out, name):
+    """transformers >= 5 returns an output object from get_*_features, older versions a tensor."""
+    if torch.is_tensor(out):
+        return out
+    return getattr(out, "pooler_output", None) if getattr(out, name, None) is None else getattr(out, name)
+
+
+@torch.no_grad()
+def get_text_features(model, processor, device, prompts, max_text_length):
+    text_inputs = processor.tokenizer(prompts, max_length=max_text_length, padding="max_length", truncation=True,
+                                      return_attention_mask=True, return_tensors="pt").to(device)
+    if hasattr(model, "get_text_features"):
+        feats = _features(model.get_text_features(input_ids=text_inputs["input_ids"],
+                                                  attention_mask=text_inputs["attention_mask"]), "text_embeds")
+    else:
+        feats = model(input_ids=text_inputs["input_ids"], attention_mask=text_inputs["attention_mask"]).text_embeds
+    return F.normalize(feats, dim=-1)
+
+
+@torch.no_grad()
+def evaluate(model, processor, loader, device, args, label_to_text=None):
+    model.eval()
+    label_to_text = label_to_text or COVIDX_LABEL_TO_TEXT
+    class_prompts = [label_to_text[i] for i in sorted(label_to_text)]
+    text_features = get_text_features(model, processor, device, class_prompts, args.max_text_length)
+    logit_scale = model.logit_scale.exp() if hasattr(model, "logit_scale") else torch.tensor(100.0, device=device)
+
+    preds, labs, embeds = [], [], []
+    for batch_idx, batch in enumerate(loader):
+        pixel_values = batch["pixel_values"].to(device)
+        if hasattr(model, "get_image_features"):
+            image_features = _features(model.get_image_features(pixel_values=pixel_values), "image_embeds")
+        else:
+            image_features = model(pixel_values=pixel_values).image_embeds
+        image_features = F.normalize(image_features, dim=-1)
+        logits = logit_scale * image_features @ text_features.t()
+        preds.append(torch.argmax(logits, dim=-1))
+        labs.append(batch["labels"].to(device))
+        embeds.append(image_features)                       # stays on the device (the reference moves it to the host)
+        if (batch_idx + 1) % 10 == 0:
+            print(f"Processed {(batch_idx + 1) * args.eval_batch_size} images...")
+    labels = torch.cat(labs).long()
+    embeds = torch.cat(embeds, dim=0).float()
+    all_predictions, all_labels = torch.cat(preds).cpu().numpy(), labels.cpu().numpy()
+
+    p, r, f, _ = _prf(all_labels, all_predictions)          # sklearn macro averages, zero_division=0
+    zs = {"accuracy": float(np.mean(all_predictions == all_labels) * 100.0), "precision_macro": float(p.mean() * 100.0),
+          "recall_macro": float(r.mean() * 100.0), "f1_macro": float(f.mean() * 100.0)}
+    print("\n>> Zero-shot Classification Metrics:")
+    print(f"   Accuracy: {zs['accuracy']:.2f}%")
+    print(f"   Precision (macro): {zs['precision_macro']:.2f}%")
+    print(f"   Recall (macro): {zs['recall_macro']:.2f}%")
+    print(f"   F1 (macro): {zs['f1_macro']:.2f}%")
+
+    # dists = embeds @ embeds.t(), diagonal -inf (eval_medsiglip.py:238-239): one resident index + exact full ranking
+    ranks, _ = rank_self(embeds, "cosine")
+    k_values = [1, 5, 10, 15, 20]
+    head = ranks[:, :max(k_values)].cpu().numpy()
+    kappas = [1, 5, 10]
+    accuracy = torch.stack(retrieval_accuracy(None, all_labels, topk=kappas, topk_ids=head[:, :max(kappas)])).cpu().numpy()
+    print(f">> R@K{kappas}: {np.around(accuracy, 2)}%")
+    m_ap, aps, pr, _ = compute_map(ranks.t(), all_labels, kappas)
+    print(f">> mAP: {m_ap * 100.0:.2f}%")
+    print(f">> mP@K{kappas}: {np.around(pr * 100.0, 2)}%")
+    print("\n>> Retrieval Classification Metrics (Majority Voting):")
+    classification_results = compute_classification_metrics(all_labels, None, k_values, ranks=head.T)
+    for k in k_values:
+        m = classification_results[k]
+        print(f"\n>> Top-{k} Retrieved Images:")
+        print(f"   Accuracy: {m['accuracy']:.2f}%")
+        print(f"   Precision (macro): {m['precision_macro']:.2f}%")
+        print(f"   Recall (macro): {m['recall_macro']:.2f}%")
+        print(f"   F1 (macro): {m['f1_macro']:.2f}%")
+    return {"zero_shot": zs, "predictions": all_predictions, "labels": all_labels, "text_features": text_features,
+            "embeds": embeds, "ranks": ranks, "acc": accuracy, "mAP": m_ap, "aps": aps, "pr": pr,
+            "classification": classification_results}

@@ -436,25 +436,6 @@ def _linear_w3(mod):
     return cached[1]
 
 
-def _accelerate_linears(root):
-    """Route every nn.Linear under `root` (third-party module trees: the transformers SigLIP tower) through
-    mirx_linear_split3 for CUDA fp32 inference; anything else (training, CPU, odd widths) takes the module's
-    own forward."""
-    for mod in root.modules():
-        if type(mod) is nn.Linear and not getattr(mod, "_mirx_routed", False):
-            def fwd(x, _m=mod, _orig=mod.forward):
-                if not _linear_s3_ok(_m, x):
-                    return _orig(x)
-                bf = getattr(_m, "_mirx_in_bound", None)            # set where the input range is provable
-                if bf is not None:
-                    bound = bf()
-                    if _linear_h2_ok(_m, x, bound):
-                        return _linear_h2(_m, x, bound)
-                return _linear_s3(_m, x)
-            mod.forward = fwd
-            mod._mirx_routed = True
-
-
 SPLIT2H_LINEAR = True    # Linears fed by a LayerNorm: two fp16 terms per operand (3 MFMAs per product) instead of three bf16
 
 
@@ -539,80 +520,6 @@ def _linear_h2(mod, x, bound, act=0, res=None, gamma=None, out=None):
     return out
 
 
-class _PackedQKV:
-    """q_proj / k_proj / v_proj of a third-party attention module seen as ONE Linear [3C, C]: its output is the
-    packed [B, N, 3, heads, head_dim] tensor mirx_attention_qkv_f32 reads (duck-typed for _linear_s3)."""
-
-    def __init__(self, att):
-        self.att = att
-        self.in_features = att.q_proj.in_features
-        self.out_features = 3 * att.q_proj.out_features
-        self._key = None
-
-    def _refresh(self):
-        ws = (self.att.q_proj.weight, self.att.k_proj.weight, self.att.v_proj.weight)
-        key = tuple((w.data_ptr(), w._version) for w in ws)
-        if key != self._key:
-            self.weight = torch.cat([w.detach() for w in ws], 0)
-            bs = (self.att.q_proj.bias, self.att.k_proj.bias, self.att.v_proj.bias)
-            self.bias = None if bs[0] is None else torch.cat([b.detach() for b in bs], 0)
-            self._key = key
-
-
-_FUSED_TOWER_ATTENTION = [False]        # set by MedSigLIP.forward only: other callers may ask for attention maps
-
-
-def _route_tower_attention(root):
-    """transformers SiglipAttention (q/k/v/out projections around softmax(q k^T / sqrt(d)) v): for CUDA fp32
-    inference without mask, run packed-qkv Linear -> mirx_attention_qkv_f32 -> out Linear.  Only while
-    _FUSED_TOWER_ATTENTION is set (the embedding forward): the module's own forward still serves callers that
-    read attention weights (the reference's rollout explainer, model.py:546-551)."""
-    for mod in root.modules():
-        if (mod.__class__.__name__ == "SiglipAttention" and not getattr(mod, "_mirx_routed", False)
-                and all(hasattr(mod, a) for a in ("q_proj", "k_proj", "v_proj", "out_proj", "head_dim", "scale"))):
-            packed = _PackedQKV(mod)
-
-            def fwd(hidden_states, attention_mask=None, _m=mod, _orig=mod.forward, _p=packed, **kw):
-                x = hidden_states
-                if (_FUSED_TOWER_ATTENTION[0] and attention_mask is None and x.dim() == 3
-                        and _m.head_dim in (32, 64, 72, 96) and _linear_s3_ok(_p, x) and x.shape[0] <= 65535):
-                    _p._refresh()
-                    b, n, c = x.shape
-                    bf = getattr(_m, "_mirx_in_bound", None)
-                    bound = bf() if bf is not None else float("inf")
-                    qkv = _linear_h2(_p, x, bound) if _linear_h2_ok(_p, x, bound) else _linear_s3(_p, x)
-                    a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
-                    with torch.cuda.device(x.device):
-                        lib = _lib.load()
-                        att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
-                        _lib.check(att(_ptr(qkv), b, n, c // _m.head_dim, _m.head_dim, float(_m.scale), _ptr(a),
-                                       _stream(x.device)), "mirx_attention_qkv_f32")
-                    return _m.out_proj(a), None
-                return _orig(hidden_states, attention_mask, **kw)
-
-            mod.forward = fwd
-            mod._mirx_routed = True
-
-
-def _attach_tower_bounds(root):
-    """Input bounds for the Linears of transformers' SiglipEncoderLayer (pre-LN blocks): q / k / v and fc1 read a
-    LayerNorm output; out_proj reads softmax-weighted averages of V rows; fc2 reads gelu(fc1 output), |gelu(v)| <= |v|."""
-    for layer in root.modules():
-        if layer.__class__.__name__ != "SiglipEncoderLayer":
-            continue
-        try:
-            ln1, ln2, sa, mlp = layer.layer_norm1, layer.layer_norm2, layer.self_attn, layer.mlp
-            q, k, v, o, f1, f2 = sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj, mlp.fc1, mlp.fc2
-        except AttributeError:
-            continue
-        for lin in (q, k, v):
-            lin._mirx_in_bound = (lambda _ln=ln1: _layernorm_bound(_ln))
-        sa._mirx_in_bound = (lambda _ln=ln1: _layernorm_bound(_ln))
-        o._mirx_in_bound = (lambda _ln=ln1, _v=v: _linear_out_bound(_ln, _v))
-        f1._mirx_in_bound = (lambda _ln=ln2: _layernorm_bound(_ln))
-        f2._mirx_in_bound = (lambda _ln=ln2, _f=f1: _linear_out_bound(_ln, _f))
-
-
 def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
     """[HIP] y = epi(x W^T + b) through mirx_linear_split3 (include/mirx.h); x: [..., k] fp32 CUDA.
     act=1: GELU; res/gamma: y = res + gamma * v (may be written in place with out=res)."""
@@ -630,6 +537,96 @@ def _linear_s3(mod, x, act=0, res=None, gamma=None, out=None):
                                                   _ptr(gamma.detach()) if gamma is not None else None, _ptr(out),
                                                   _stream(x.device)), "mirx_linear_split3")
     return out
+
+
+def _linear_auto(mod, x, act=0):
+    """nn.Linear forward that takes the MFMA kernel for CUDA fp32 inference (any [..., k] input, k % 16 == 0) and the
+    module's own forward otherwise.  act: 0 none, 1 erf-GELU, 2 tanh-GELU (fused in the kernel's epilogue)."""
+    if _linear_s3_ok(mod, x):
+        return _linear_s3(mod, x, act=act)
+    y = mod(x)
+    return y if act == 0 else F.gelu(y, approximate="tanh" if act == 2 else "none")
+
+
+def _layernorm(ln, x, tokens_per_image=0):
+    """nn.LayerNorm over the last axis: [HIP] mirx_layernorm for CUDA fp32 inference, F.layer_norm otherwise.
+    tokens_per_image > 0: x is [images * tpi, c] and the result comes back channels-first [images, c, tpi]."""
+    c = ln.normalized_shape[-1]
+    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c % 4 == 0
+            and len(ln.normalized_shape) == 1 and x.shape[-1] == c):
+        x = x.contiguous()
+        m = x.numel() // c
+        if tokens_per_image:
+            out = torch.empty((m // tokens_per_image, c, tokens_per_image), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().mirx_layernorm(_ptr(x), m, c, _ptr(ln.weight.detach()) if ln.weight is not None else None,
+                                                  _ptr(ln.bias.detach()) if ln.bias is not None else None, float(ln.eps),
+                                                  _ptr(out), int(tokens_per_image), _stream(x.device)), "mirx_layernorm")
+        return out
+    y = F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+    if tokens_per_image:
+        y = y.view(-1, tokens_per_image, c).transpose(1, 2).contiguous()
+    return y
+
+
+class _ConvAsLinear:
+    """A Conv2d whose kernel equals its stride (non-overlapping patches) seen as a Linear over patch rows: weight =
+    conv.weight.flatten(1) zero-padded to a multiple of 16 input features (duck-typed for _linear_s3 / _linear_h2)."""
+
+    def __init__(self, conv):
+        self.conv = conv
+        self._key = None
+
+    def refresh(self):
+        w, b = self.conv.weight, self.conv.bias
+        key = (w.data_ptr(), w._version, None if b is None else b._version)
+        if key != self._key:
+            flat = w.detach().flatten(1)
+            k = flat.shape[1]
+            self.k = k
+            self.in_features = (k + 15) // 16 * 16
+            self.out_features = flat.shape[0]
+            self.weight = F.pad(flat, (0, self.in_features - k)) if self.in_features != k else flat.contiguous()
+            self.bias = None if b is None else b.detach()
+            self._key = key
+        return self
+
+
+def _conv_patch_tokens(conv, x, ln2d=None, nchw_out=False):
+    """[HIP] Conv2d(kernel = stride = p, no padding) on NCHW x as mirx_patchify_nchw + the MFMA Linear kernel.
+    ln2d: an nn.LayerNorm applied over the channel axis of every pixel first (timm LayerNorm2d in front of the ConvNeXt
+    downsample conv) -- its output is bounded, so the Linear runs on two fp16 terms.  -> [B * gh * gw, cout] rows, or the
+    NCHW map [B, cout, gh, gw] when nchw_out."""
+    pl = conv.__dict__.get("_mirx_as_linear")
+    if pl is None:
+        pl = _ConvAsLinear(conv)
+        conv.__dict__["_mirx_as_linear"] = pl
+    pl.refresh()
+    p = conv.kernel_size[0]
+    b, c, h, w = x.shape
+    gh, gw = h // p, w // p
+    x = x.contiguous()
+    rows = torch.empty((b * gh * gw, pl.in_features), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        st = _stream(x.device)
+        _lib.check(lib.mirx_patchify_nchw(_ptr(x), b, c, h, w, p, _ptr(ln2d.weight.detach()) if ln2d is not None else None,
+                                          _ptr(ln2d.bias.detach()) if ln2d is not None else None,
+                                          float(ln2d.eps) if ln2d is not None else 0.0, _ptr(rows), pl.in_features, st),
+                   "mirx_patchify_nchw")
+        if nchw_out:
+            out = torch.empty((b, pl.out_features, gh, gw), dtype=torch.float32, device=x.device)
+            _lib.check(lib.mirx_linear_split3_nchw(_ptr(rows), b, gh * gw, pl.in_features, _ptr(_linear_w3(pl)),
+                                                   _ptr(pl.bias) if pl.bias is not None else None, pl.out_features, None, None,
+                                                   _ptr(out), st), "mirx_linear_split3_nchw")
+            return out
+    if ln2d is not None:
+        bound = _layernorm_bound(ln2d)
+        if _linear_h2_ok(pl, rows, bound):
+            return _linear_h2(pl, rows, bound)
+    return _linear_s3(pl, rows)
 
 
 class DenseNet121(nn.Module):
@@ -940,7 +937,7 @@ class _CnxBlock(nn.Module):
             # fc2 written back NCHW with the skip added in its epilogue
             lib = _lib.load()
             b, c, h, w = x.shape
-            yn = self.norm(y)
+            yn = _layernorm(self.norm, y)
             bn = _layernorm_bound(self.norm)                               # fc1 reads a LayerNorm output
             hid = (_linear_h2(mlp.fc1, yn, bn, act=1) if _linear_h2_ok(mlp.fc1, yn, bn)
                    else _linear_s3(mlp.fc1, yn, act=1))                    # [b, h, w, 4c]
@@ -972,7 +969,15 @@ class _CnxStage(nn.Module):
         self.blocks = nn.Sequential(*[_CnxBlock(cout) for _ in range(depth)])
 
     def forward(self, x):
-        return self.blocks(self.downsample(x))
+        ds = self.downsample
+        if (isinstance(ds, nn.Sequential) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and x.shape[0] <= 65535 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and SPLIT3_LINEAR):
+            # MI355X path: LayerNorm2d + the NCHW -> patch-row gather in one HIP pass, the 2x2/2 conv as an MFMA Linear
+            # that writes the next stage's NCHW map
+            x = _conv_patch_tokens(ds[1], x, ln2d=ds[0], nchw_out=True)
+        else:
+            x = ds(x)
+        return self.blocks(x)
 
 
 class _CnxHead(nn.Module):
@@ -981,6 +986,8 @@ class _CnxHead(nn.Module):
         self.norm = _LayerNorm2d(dim, eps=CNX_EPS)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            return _layernorm(self.norm, x.mean(dim=(2, 3)))
         return torch.flatten(self.norm(x.mean(dim=(2, 3), keepdim=True)), 1)
 
 
@@ -1002,8 +1009,16 @@ class _ConvNeXtV2Backbone(nn.Module):
                 nn.init.trunc_normal_(m.weight, std=0.02)
                 nn.init.zeros_(m.bias)
 
+    def _stem(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and SPLIT3_LINEAR
+                and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0):
+            b, _, h, w = x.shape
+            tok = _conv_patch_tokens(self.stem[0], x)                          # [b * h/4 * w/4, 128]
+            return _layernorm(self.stem[1], tok, tokens_per_image=(h // 4) * (w // 4)).view(b, -1, h // 4, w // 4)
+        return self.stem(x)
+
     def forward(self, x):
-        return self.head(self.stages(self.stem(x)))
+        return self.head(self.stages(self._stem(x)))
 
 
 class ConvNeXtV2(nn.Module):
@@ -1108,7 +1123,7 @@ class _VitBlock(nn.Module):
             x = x.contiguous()
             # the two Linears fed by a LayerNorm have a provable input bound: two fp16 terms (3 MFMAs per product)
             b1, b2 = _layernorm_bound(self.norm1), _layernorm_bound(self.norm2)
-            h1 = self.norm1(x)
+            h1 = _layernorm(self.norm1, x)
             qkv = _linear_h2(at.qkv, h1, b1) if _linear_h2_ok(at.qkv, h1, b1) else _linear_s3(at.qkv, h1)
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
@@ -1127,7 +1142,7 @@ class _VitBlock(nn.Module):
             ba = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
             x = (_linear_h2(at.proj, a, ba, res=x, gamma=self.ls1.gamma) if _linear_h2_ok(at.proj, a, ba)
                  else _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma))
-            h2 = self.norm2(x)
+            h2 = _layernorm(self.norm2, x)
             hid = (_linear_h2(self.mlp.fc1, h2, b2, act=1) if _linear_h2_ok(self.mlp.fc1, h2, b2)
                    else _linear_s3(self.mlp.fc1, h2, act=1))
             bh = _linear_out_bound(self.norm2, self.mlp.fc1)                 # |gelu(v)| <= |v|
@@ -1144,6 +1159,9 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and SPLIT3_LINEAR:
+            # MI355X path: the stride-14 patch convolution as patch gather + MFMA Linear (no library convolution)
+            return _conv_patch_tokens(self.proj, x).view(x.shape[0], -1, self.proj.out_channels)
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
@@ -1180,7 +1198,7 @@ class _Dinov2Backbone(nn.Module):
         gh, gw = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
         x = self.patch_embed(x)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self._pos(gh, gw)
-        return self.norm(self.blocks(x))
+        return _layernorm(self.norm, self.blocks(x))
 
     def forward(self, x):
         return self.forward_features(x)[:, 0]
@@ -1276,22 +1294,14 @@ class ConvNeXtV2MultiLabelRetrievalModel(nn.Module):
 # transformers class is built from a LOCAL config, so `backbone.*` / `projection.*` checkpoints
 # load unchanged and nothing is fetched.
 # =================================================================================================
-MEDSIGLIP_VISION = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
-                        image_size=448, patch_size=14)
-
-
 class MedSigLIP(nn.Module):
+    """Reference model.py:536-634: `backbone` (the SigLIP vision tower), `projection`, unit-norm output."""
+
     def __init__(self, model_name="google/medsiglip-448", embed_dim=512, unfreeze_layers=2, vision_config=None,
                  weights=None):
         super().__init__()
-        try:
-            from transformers import SiglipVisionConfig, SiglipVisionModel
-        except Exception as e:  # pragma: no cover
-            raise RuntimeError("MedSigLIP needs the `transformers` package (a reference dependency)") from e
-        cfg = SiglipVisionConfig(**(vision_config or MEDSIGLIP_VISION))
-        cfg._attn_implementation = "eager"          # the reference forces eager attention (model.py:546-551)
-        tower = SiglipVisionModel(cfg)
-        self.backbone = getattr(tower, "vision_model", tower)   # transformers < 5 wraps the tower once more
+        from .siglip import MEDSIGLIP_VISION, SiglipVisionTower
+        self.backbone = SiglipVisionTower(**(vision_config or MEDSIGLIP_VISION))
         for p in self.backbone.parameters():
             p.requires_grad = False
         if unfreeze_layers > 0:
@@ -1302,9 +1312,6 @@ class MedSigLIP(nn.Module):
                 p.requires_grad = True
         hidden = self.backbone.config.hidden_size
         self.projection = nn.Sequential(nn.Linear(hidden, 512), nn.LayerNorm(512), nn.ReLU(), nn.Linear(512, embed_dim))
-        _accelerate_linears(self)                      # q/k/v/out projections, MLPs (4304 wide: padded tile), head
-        _route_tower_attention(self.backbone)          # head_dim 72 flash attention on the packed projection
-        _attach_tower_bounds(self.backbone)            # provable input ranges -> two-fp16-term Linear kernel
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             for key in ("state-dict", "state_dict"):
@@ -1313,7 +1320,7 @@ class MedSigLIP(nn.Module):
             self.load_state_dict(sd, strict=False)
 
     def ensure_eager_attention(self):
-        """Kept for callers (milvus_retrieval.py:172); the tower is built eager already."""
+        """Kept for callers (milvus_retrieval.py:172); attention maps always come from the explicit softmax path."""
         self.backbone.config._attn_implementation = "eager"
 
     def verify_attention_output(self, device="cuda"):
@@ -1325,12 +1332,10 @@ class MedSigLIP(nn.Module):
         return out.attentions is not None and len(out.attentions) > 0 and out.attentions[0].numel() > 0
 
     def forward(self, x):
-        _FUSED_TOWER_ATTENTION[0] = True               # embedding extraction never reads attention maps
-        try:
-            features = self.backbone(pixel_values=x).pooler_output
-        finally:
-            _FUSED_TOWER_ATTENTION[0] = False
-        return _normalize_rows(self.projection(features))
+        features = self.backbone(pixel_values=x).pooler_output
+        p = self.projection
+        h = torch.relu(_layernorm(p[1], _linear_auto(p[0], features)))
+        return _normalize_rows(_linear_auto(p[3], h))
 
 
 def build_model(model_type, embedding_dim=None, **kw):

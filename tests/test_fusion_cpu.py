@@ -33,26 +33,27 @@ def test_file_sources_read_the_reference_formats():
     np.testing.assert_array_equal(al.dino_embeddings.astype(np.float64), np.asarray(w["dino_embeddings"]))
 
 
-def test_alignment_errors_like_the_reference(tmp_path):
+def test_alignment_error_conditions_of_the_reference(tmp_path):
+    """Same error CONDITIONS and exception type (ValueError) as fusion_eval/align.py; the wording is this build's own."""
     from mirx import fusion as mf
     e = np.eye(3, dtype=np.float32)
     mf.save_embedding_file(tmp_path / "a.npz", ["x", "y", "z"], ["l0", "l1", "l0"], e)
     mf.save_embedding_file(tmp_path / "b.json", ["x", "y", "q"], ["l0", "OTHER", "l0"], e)
     a, b = mf.FileEmbeddingSource(tmp_path / "a.npz", "a"), mf.FileEmbeddingSource(tmp_path / "b.json", "b")
-    with pytest.raises(ValueError, match="Label mismatch for image_path=y"):
+    with pytest.raises(ValueError, match="y: the sources disagree on the label"):
         mf.align_embedding_sources(a, b)
     al = mf.align_embedding_sources(a, b, strict_label_check=False)
     assert al.image_paths == ["x", "y"] and al.labels == ["l0", "l1"]
     assert al.coverage["present_in_conv_only"] == ["z"] and al.coverage["present_in_dino_only"] == ["q"]
     mf.save_embedding_file(tmp_path / "dup.npz", ["x", "x"], ["l0", "l0"], e[:2])
-    with pytest.raises(ValueError, match="Duplicate image_path found in ConvNeXt: x"):
+    with pytest.raises(ValueError, match="ConvNeXt: image_path 'x' occurs more than once"):
         mf.align_embedding_sources(mf.FileEmbeddingSource(tmp_path / "dup.npz", "d"), b)
     mf.save_embedding_file(tmp_path / "none.npz", ["u"], ["l0"], e[:1])
-    with pytest.raises(ValueError, match="No aligned samples"):
+    with pytest.raises(ValueError, match="share no image_path"):
         mf.align_embedding_sources(mf.FileEmbeddingSource(tmp_path / "none.npz", "n"), b)
-    with pytest.raises(ValueError, match="Unsupported embedding file format"):
+    with pytest.raises(ValueError, match="embedding dumps are .npz or .json"):
         mf.FileEmbeddingSource(tmp_path / "a.csv", "a").fetch_all()
-    with pytest.raises(ValueError, match="Unsupported source type"):
+    with pytest.raises(ValueError, match="unknown embedding source type"):
         mf.build_embedding_source({"type": "parquet"})
     # query-set restriction keeps the query file's order (align.py:176-178)
     (tmp_path / "q.txt").write_text("# comment\ny label\nmissing\nx\n")
@@ -87,9 +88,9 @@ def test_matrix_helpers_match_oracle():
     got = mf.confidence_based_fusion(cs, ds)
     np.testing.assert_array_equal(got["similarity"], z["d24_d16_conf_similarity"])
     assert [got["conv_selected_queries"], got["dino_selected_queries"]] == z["d24_d16_conf_counts"].tolist()
-    with pytest.raises(ValueError, match="Unsupported score normalization mode"):
+    with pytest.raises(ValueError, match="use one of none, zscore, minmax"):
         mf.normalize_similarity_matrix(cs, "softmax")
-    with pytest.raises(ValueError, match="same shape"):
+    with pytest.raises(ValueError, match="differ in shape"):
         mf.confidence_based_fusion(cs, ds[:5])
     with pytest.raises(ValueError, match="at least two"):
         mf.top12_margin(cs[:, :1])
