@@ -12,10 +12,19 @@ ALL N*queries embeddings against the local gallery shard (1M/N rows; bf16 MFMA c
 fp64 re-rank in libmirx), one all-gather of the per-shard candidates, merge.  Per-GPU work is
 constant in N (weak scaling): value = N * queries * steps / max-over-ranks time.
 
+`--embed-streams S` splits a micro-batch over S HIP streams (the ~250 dependent kernels of a forward leave tails that
+another stream's forward fills).  For N > 1 the line carries per-stage times (embed / gather_q / search / gather_cand /
+merge, rank 0 and the maximum over ranks) so that a scaling curve can be read stage by stage.
+
 Extra objects on the JSON line (tier contract):
   roofline      the distance GEMM (k_gemm filter pass): algorithmic 2*Q*N_shard*D FLOP per
                 launch / its HIP-event duration measured inside the timed steps, vs the dense
                 bf16 MFMA peak 2516.6 TFLOP/s (256 CU x 2.4 GHz x 4096 FLOP/clk/CU).
+  roofline_embed  the embed stage's dominant kernel family (the fused 1x1 convolutions, two fp16 terms): HBM-bound --
+                algorithmic bytes (each launch reads its input prefix once and writes its output once) / HIP-event time,
+                vs 8 TB/s; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE from the committed PMC passes of the same forward.
+  extras        (N = 1) images/s of the other backbones at their native resolutions (ConvNeXtV2-base 384, DINOv2 ViT-B/14
+                518, MedSigLIP 448) and search-only queries/s over 1M x 256 / 512 galleries, measured in this run.
   cpu_baseline  the reference's CPU path re-created with the same torch calls
                 (`-torch.cdist` + topk, test.py:1080,44) and the oracle DenseNet restatement,
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
@@ -45,7 +54,10 @@ def parse():
     ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (all GPUs)")
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--queries", type=int, default=4096, help="queries (images) per GPU per step")
-    ap.add_argument("--embed-batch", type=int, default=2048)
+    ap.add_argument("--embed-batch", type=int, default=4096)
+    ap.add_argument("--embed-streams", type=int, default=2, help="HIP streams one micro-batch is split over")
+    ap.add_argument("--search-chunks", type=int, default=1, help="N > 1: pieces of the local search whose candidate all-gathers overlap the next piece")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other-backbone / other-dimension measurements")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +141,72 @@ def cpu_baseline(index, model, args, dev):
                       f"torch CPU threads={nthreads}, os.cpu_count={os.cpu_count()}"}
 
 
+def profile_traffic(name, key):
+    """Per-launch (or per-forward) fabric-side bytes from the committed PMC summary profiles/r02_pmc_traffic.json
+    (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2 on gfx950)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        d = json.load(fh)
+    return d.get(name, {}).get(key)
+
+
+def timed_images_per_s(model, x, iters, warmup=2):
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(x)
+        torch.cuda.synchronize()
+    return x.shape[0] * iters / (time.perf_counter() - t0)
+
+
+def extras(args, dev):
+    """Configs 3-5 of BASELINE.json on this GPU (embed stage, native resolution, fp32, synthetic images, random-init
+    weights) and the search stage at their embedding widths over a 1M-row gallery."""
+    from mirx import _lib
+    from mirx.index import FlatIndex
+    from mirx.model import ConvNeXtV2, DinoV2, MedSigLIP
+    out = {}
+    for name, ctor, size, batch, iters in (("convnextv2_base_384", lambda: ConvNeXtV2(embedding_dim=256), 384, 64, 4),
+                                           ("dinov2_vitb14_518", lambda: DinoV2(embedding_dim=256), 518, 32, 4),
+                                           ("medsiglip_448", lambda: MedSigLIP(embed_dim=512), 448, 16, 4)):
+        torch.manual_seed(0)
+        m = ctor().eval().to(dev)
+        x = synthetic_images(batch, size, 99, dev)
+        ips = timed_images_per_s(m, x, iters)
+        out[name] = {"images_per_s": ips, "batch": batch, "image_size": size, "dtype": "f32 (two fp16 / three bf16 MFMA terms)",
+                     "data": "synthetic images, random-init weights",
+                     "traffic_per_forward": profile_traffic(name, "bytes_per_forward"),
+                     "dominant_kernel": profile_traffic(name, "dominant_kernel")}
+        del m, x
+        torch.cuda.empty_cache()
+    for dim in (256, 512):
+        ix = FlatIndex(dim, "COSINE", dev.index)
+        build_shard(ix, 0, args.gallery, dim, dev)
+        ix.set_option(_lib.OPT_PROFILE, 1)
+        q = torch.nn.functional.normalize(
+            torch.randn((4096, dim), generator=torch.Generator(device=dev).manual_seed(4321), device=dev), dim=1)
+        ix.search(q, args.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ix.search(q, args.k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        gm = ix.last_timings()["gemm"]
+        dimp = (dim + 127) // 128 * 128
+        tf = 2.0 * 4096 * args.gallery * dimp / (gm * 1e-3) / 1e12 if gm > 0 else 0.0
+        out[f"search_only_{args.gallery}x{dim}"] = {"queries_per_s": 4096 / dt, "ms_per_4096_queries": dt * 1e3, "gemm_ms": gm,
+                                                    "gemm_tflops": tf, "gemm_frac_of_bf16_peak": tf / MFMA_BF16_PEAK_TFLOPS}
+        del ix
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,23 +243,50 @@ def main():
     lo, hi = shard_bounds(args.gallery, world, rank)
     build_shard(index, lo, hi, args.dim, dev)
     index.set_option(_lib.OPT_PROFILE, 1)
+    args.embed_batch = min(args.embed_batch, args.queries)
     nmb = max(1, args.queries // args.embed_batch)
     q_local = nmb * args.embed_batch
-    pool = [synthetic_images(args.embed_batch, args.image_size, 1234 + 97 * rank + i, dev) for i in range(min(4, nmb))]
+    pool = [synthetic_images(args.embed_batch, args.image_size, 1234 + 97 * rank + i, dev) for i in range(min(2, nmb))]
     fixed_q = torch.nn.functional.normalize(
         torch.randn((q_local, args.dim), generator=torch.Generator(device=dev).manual_seed(4321 + rank), device=dev), dim=1)
     searcher = ShardedSearcher(lambda qa, kk: index.search(qa, kk, return_f64=True), "COSINE")
     emb = torch.empty((q_local, args.dim), dtype=torch.float32, device=dev)
-    gemm_ms, stage_ms = [], {}
+    gemm_ms, stage_ms, stage_ev = [], {}, {}
+    nstr = max(1, args.embed_streams)
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstr)] if nstr > 1 and args.embed_batch % nstr == 0 else None
+
+    def embed_all():
+        """Every micro-batch through the DenseNet; with side streams its halves run concurrently (each forward is a chain
+        of ~250 dependent kernels whose tails the other stream's kernels fill)."""
+        cur = torch.cuda.current_stream(dev)
+        for i in range(nmb):
+            x = pool[i % len(pool)]
+            dst = emb[i * args.embed_batch:(i + 1) * args.embed_batch]
+            if side is None:
+                dst.copy_(model(x))
+                continue
+            part = args.embed_batch // len(side)
+            for j, st in enumerate(side):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    dst[j * part:(j + 1) * part] = model(x[j * part:(j + 1) * part])
+            for st in side:
+                cur.wait_stream(st)
 
     def step(record):
+        ev = stage_ev if record else None
         with torch.no_grad():
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
             if args.search_only:
                 emb.copy_(fixed_q)
             else:
-                for i in range(nmb):
-                    emb[i * args.embed_batch:(i + 1) * args.embed_batch] = model(pool[i % len(pool)])
-            out = searcher.search(emb, args.k)
+                embed_all()
+            e1.record()
+            if record:
+                stage_ev.setdefault("embed", []).extend([(True, e0), (False, e1)])
+            out = searcher.search(emb, args.k, chunks=args.search_chunks if world > 1 else 1, events=ev)
         if record:
             t = index.last_timings()          # waits for this search's events only
             gemm_ms.append(t["gemm"])
@@ -208,36 +313,69 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- per-stage times of the timed steps (events recorded on the compute stream; an asynchronous collective shows
+    # its launch-side time only) ------------------------------------------------------------------------
+    names = ["embed", "gather_q", "search", "gather_cand", "merge"]
+    mine = []
+    for nm in names:
+        pairs = stage_ev.get(nm, [])
+        tot, begin = 0.0, None
+        for is_begin, ev in pairs:
+            if is_begin:
+                begin = ev
+            elif begin is not None:
+                tot += begin.elapsed_time(ev)
+                begin = None
+        mine.append(tot / max(1, args.steps))
+    stage_rank0, stage_max = mine, mine
+    if world > 1:
+        tt = torch.tensor(mine, dtype=torch.float64, device=dev)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.broadcast(tt, src=0)
+        stage_rank0, stage_max = tt.tolist(), mx.tolist()
+
     total_q = world * q_local * args.steps
     stats = index.last_stats()
     embed_roof = None
     if rank == 0 and not args.search_only:
-        # calibration pass OUTSIDE the timed region: HIP events around every launch of the embed
-        # stage's dominant hand-written kernel (the fused fp32-MFMA 1x1 convolution)
+        # calibration pass OUTSIDE the timed region: HIP events around every launch of the embed stage's dominant
+        # hand-written kernel family (the fused 1x1 convolutions of the 58 dense layers and 3 transitions)
         model.conv1x1_timer = []
+        xcal = pool[0][:min(args.embed_batch, 2048)]
         with torch.no_grad():
-            model(pool[0])
+            model(xcal)
         torch.cuda.synchronize(dev)
         ms = sum(a.elapsed_time(b) for a, b, _ in model.conv1x1_timer)
         fl = sum(f for _, _, f in model.conv1x1_timer)
         nl = len(model.conv1x1_timer)
         model.conv1x1_timer = None
         if ms > 0:
-            ach = fl / (ms * 1e-3) / 1e12
-            # every product of this kernel is six bf16 MFMAs (three-term split of both fp32 operands), so its
-            # matrix-pipe roofline in fp32-equivalent FLOP is the dense bf16 peak / 6
-            split3 = getattr(model, "split3_min_cin", 1 << 30) <= 64
-            peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if split3 else MFMA_F32_PEAK_TFLOPS
-            kname = ("mirx::k_conv1x1_s3 (fused BN+ReLU+1x1 conv+BN+ReLU, 3-term bf16 MFMA, fp32-grade)" if split3
-                     else "mirx::k_conv1x1 (fused BN+ReLU+1x1 conv+BN+ReLU, fp32 MFMA)")
-            embed_roof = {"bound": "mfma", "kernel": f"{kname}, {nl} launches of one {args.embed_batch}-image forward",
-                          "dtype": "f32 (3 x bf16 terms)" if split3 else "f32",
-                          "achieved": ach, "peak": peak, "unit": "TFLOP/s (fp32-equivalent)",
-                          "frac": ach / peak, "flop_per_forward": fl, "ms_per_forward": ms,
-                          "traffic": None}
+            # algorithmic bytes: a launch reads cin channels and writes cout channels of every pixel once, fp32
+            # (flop = 2 * pixels * cin * cout per launch, so bytes = 4 * pixels * (cin + cout) needs the shapes: take
+            # them from the model's own geometry)
+            from mirx.model import BLOCK_CONFIG, BN_SIZE, GROWTH, INIT_FEATURES
+            b, px, c, nbytes = xcal.shape[0], (args.image_size // 4) ** 2, INIT_FEATURES, 0.0
+            for bi, nlayers in enumerate(BLOCK_CONFIG):
+                for li in range(nlayers):
+                    nbytes += 4.0 * b * px * (c + li * GROWTH + BN_SIZE * GROWTH)
+                c += nlayers * GROWTH
+                if bi + 1 < len(BLOCK_CONFIG):
+                    px //= 4
+                    nbytes += 4.0 * b * px * (c + c // 2)
+                    c //= 2
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            tr = profile_traffic("densenet121_conv1x1", "bytes_per_image")
+            embed_roof = {"bound": "hbm",
+                          "kernel": f"mirx::k_conv1x1_h2 (fused BN+ReLU+1x1 conv+BN+ReLU, two fp16 MFMA terms, fp32-grade), "
+                                    f"{nl} launches of one {b}-image forward",
+                          "dtype": "f32 (2 x fp16 terms)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                          "algorithmic_bytes_per_forward": nbytes, "ms_per_forward": ms,
+                          "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
+                          "traffic": None if tr is None else tr * b}
     if rank == 0:
         dimp = (args.dim + 63) // 64 * 64
-        flop = 2.0 * (world * q_local) * (hi - lo) * dimp
+        flop = 2.0 * (world * q_local // max(1, args.search_chunks if world > 1 else 1)) * (hi - lo) * dimp
         avg_gemm_ms = sum(gemm_ms) / max(1, len(gemm_ms))
         achieved = flop / (avg_gemm_ms * 1e-3) / 1e12 if avg_gemm_ms > 0 else 0.0
         line = {
@@ -251,17 +389,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 embed; bf16 MFMA candidates + f64 re-rank",
+            "dtype": "f32 embed (two fp16 MFMA terms); bf16 MFMA candidates + f64 re-rank",
             "data": "synthetic (rand 224x224 ImageNet-normalised images, seed-0 random-init DenseNet-121, "
                     "unit-norm randn gallery seed 1234)",
-            "config": {"workload": f"DenseNet-121 embed {args.image_size}x{args.image_size} + exact top-{args.k} over "
-                                   f"{args.gallery}x{args.dim} fp32 gallery (cosine), {q_local} queries/GPU/step",
+            "config": {"workload": f"DenseNet-121 embed {args.image_size}x{args.image_size} (device-resident inputs) + exact "
+                                   f"top-{args.k} over {args.gallery}x{args.dim} fp32 gallery (cosine), {q_local} queries/GPU/step",
                        "gallery_rows": args.gallery, "dim": args.dim, "queries_per_gpu_per_step": q_local,
-                       "embed_batch": args.embed_batch, "k": args.k,
-                       "sharding": (f"gallery rows / {world} GPUs + 2 all-gathers" if world > 1 else "single GPU")
+                       "embed_batch": args.embed_batch, "embed_streams": len(side) if side else 1, "k": args.k,
+                       "sharding": (f"gallery rows / {world} GPUs + 2 all-gathers, search in {args.search_chunks} piece(s)"
+                                    if world > 1 else "single GPU")
                                    + (" [REHEARSAL: ranks share one GPU, gloo]" if rehearse else ""),
                        "search_stats_last_step": stats,
-                       "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}},
+                       "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+                       "pipeline_ms_per_step_rank0": dict(zip(names, stage_rank0)),
+                       "pipeline_ms_per_step_max_over_ranks": dict(zip(names, stage_max))},
             "roofline": {"bound": "mfma", "kernel": "mirx::k_gemm16<0,false> (bf16 16x16x32 MFMA distance GEMM + threshold filter)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
@@ -269,9 +410,15 @@ def main():
         }
         if embed_roof is not None:
             line["roofline_embed"] = embed_roof
-        line["roofline"]["traffic"] = gemm_traffic_from_profile(args, world, q_local)
+        if world == 1 and q_local == 4096 and args.gallery == 1_000_000 and args.dim == 1024:
+            line["roofline"]["traffic"] = profile_traffic("gemm_1Mx1024_q4096", "bytes_per_launch") or \
+                gemm_traffic_from_profile(args, world, q_local)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(index, model, args, dev)
+        if world == 1 and not args.no_extras and not args.search_only:
+            del model, index, searcher, pool
+            torch.cuda.empty_cache()
+            line["extras"] = extras(args, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

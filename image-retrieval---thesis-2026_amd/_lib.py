@@ -49,6 +49,8 @@ SYMBOLS = {
     "mirx_index_get_rows": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "mirx_index_search": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "mirx_index_search_f64": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "mirx_index_search_begin": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "mirx_index_search_end": (_int, [_vp]),
     "mirx_index_last_stats": (_int, [_vp, _vp, ctypes.POINTER(SearchStats)]),
     "mirx_index_last_timings": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "mirx_index_rank_all": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),

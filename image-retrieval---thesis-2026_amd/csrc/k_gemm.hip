@@ -246,22 +246,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
                         const float v = acc[mi][ni][r];
                         const int64_t grow = (tile_row0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * A.row_stride;
                         const bool pass = v > tau[ni] && grow < A.n_rows;
-                        if (__any(pass)) {
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                if (pass && half == h) {
-                                    const int c = lcnt[cidx];
-                                    Cand cd;
-                                    cd.s = v;
-                                    cd.row = (int32_t)grow;
-                                    if (c < A.slots) {
-                                        dst[c] = cd;
-                                    } else {
-                                        const int p = atomicAdd(&A.ovf_cnt[qcol[ni]], 1);
-                                        if (p < CAND_OVF) A.ovf[qcol[ni] * CAND_OVF + p] = cd;
-                                    }
-                                    lcnt[cidx] = c + 1;
-                                }
+                        if (pass) {
+                            // one LDS atomic per passing score: lanes l and l + 32 (the same query) get distinct slots
+                            // whatever the compiler does with the surrounding code (a plain read-modify-write of the
+                            // counter shared by two lanes is a data race it may legally merge)
+                            const int c = atomicAdd(&lcnt[cidx], 1);
+                            Cand cd;
+                            cd.s = v;
+                            cd.row = (int32_t)grow;
+                            if (c < A.slots) {
+                                dst[c] = cd;
+                            } else {
+                                const int p = atomicAdd(&A.ovf_cnt[qcol[ni]], 1);
+                                if (p < CAND_OVF) A.ovf[qcol[ni] * CAND_OVF + p] = cd;
                             }
                         }
                     }
@@ -507,13 +504,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
             } else if (__any(mx > tau[ni])) {
                 // Candidate path.  No global atomics: the region (query, this workgroup's phase, this wave
                 // row) belongs to this wave alone and its fill count lives in LDS.  The four lanes that share
-                // a query (lane & 15) claim consecutive slots in one step: rank among the passing lanes of
-                // the same query, by ballot.  Rows beyond the region's slots go to the query's overflow list.
+                // a query (lane & 15) claim slots with one LDS atomic each.  Rows beyond the region's slots go to the query's overflow list.
                 const int64_t qc = q_row0 + wn * 64 + ni * 16 + col;
                 const int cidx = (wn * 64 + ni * 16 + col) * WARPS_M + wm;
                 Cand *dst = A.cand + (qc * A.regions + region) * A.slots;
-                const unsigned long long mine = 0x0001000100010001ull << col;
-                const unsigned long long below = mine & ((1ull << el) - 1ull);
 #pragma unroll
                 for (int mi = 0; mi < M_REP; ++mi) {
                     if (!__any(mrow[mi] > tau[ni])) continue;
@@ -522,22 +516,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                         const float v = acc[mi][ni][r];
                         const int64_t grow = (tile_row0 + mi * 16 + 4 * quad + r) * A.row_stride;
                         const bool pass = v > tau[ni] && (!partial || grow < A.n_rows);
-                        const unsigned long long pm = __ballot(pass);
-                        if (pm != 0) {
-                            const int base = lcnt[cidx];
-                            if (pass) {
-                                const int c = base + __popcll(pm & below);
-                                Cand cd;
-                                cd.s = v;
-                                cd.row = (int32_t)grow;
-                                if (c < A.slots) {
-                                    dst[c] = cd;
-                                } else {
-                                    const int p = atomicAdd(&A.ovf_cnt[qc], 1);
-                                    if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
-                                }
-                                if ((pm & mine & ~((2ull << el) - 1ull)) == 0)        // last passing lane of this query
-                                    lcnt[cidx] = base + __popcll(pm & mine);
+                        if (pass) {
+                            // one LDS atomic per passing score: the four lanes that share a query get distinct slots
+                            // (a plain load / store of the shared counter would be a data race across lanes)
+                            const int c = atomicAdd(&lcnt[cidx], 1);
+                            Cand cd;
+                            cd.s = v;
+                            cd.row = (int32_t)grow;
+                            if (c < A.slots) {
+                                dst[c] = cd;
+                            } else {
+                                const int p = atomicAdd(&A.ovf_cnt[qc], 1);
+                                if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
                             }
                         }
                     }
@@ -589,6 +579,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     }
     // diagnostic builds: -DMIRX_EXP_SLOTS=0 no DMA slots at all, =1 slot branches present but never taken
     // (results wrong either way); -DMIRX_EXP_CYCLES prints K-loop cycles per K-tile
+#ifndef MIRX_GEMM_A_AUX
+#define MIRX_GEMM_A_AUX 0          // cache policy of the gallery DMA (2 = nt: stream past the L2-resident query tiles)
+#endif
 #if defined(MIRX_EXP_SLOTS) && MIRX_EXP_SLOTS == 1
 #define MIRX_SLOT_COND(G) (grp == (G) && A.dimp < 0)
 #else
@@ -601,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #define MIRX_SLOT_A(G, P)                                                           \
     if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, LDS_PTR(dma_a + (P) * 8192), 16, voff_a, \
-                                                 dma_koff + (P) * pstride_a, 0, 0);
+                                                 dma_koff + (P) * pstride_a, 0, MIRX_GEMM_A_AUX);
 #define MIRX_SLOT_B(G, P)                                                           \
     if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(dma_b + (P) * 8192), 16, voff_b, \

@@ -80,6 +80,20 @@ struct mirx_index {
     mirx_search_stats *stats_dev = nullptr;
     int *fail_count_host = nullptr;       // pinned
     mirx_search_stats stats_host{};
+    // a search whose first pass is enqueued and whose counters have not been read yet (search_begin / search_end)
+    struct Pending {
+        bool active = false;
+        int64_t nb = 0;
+        int k = 0;
+        const int64_t *exb = nullptr;
+        double *ofb = nullptr;
+        int64_t *oib = nullptr;
+        float *ovb = nullptr;
+        hipStream_t st = nullptr;
+        mirx::GemmArgs ga{};
+        mirx::FinalizeArgs fa{};
+    } pend;
+    hipEvent_t pend_ev = nullptr;
 };
 
 namespace {
@@ -210,9 +224,215 @@ int exact_pass(mirx_index *ix, const float *q32p, const int32_t *list_dev, int64
     return MIRX_OK;
 }
 
+// One internal batch (<= QUERY_BATCH queries), first half: everything that needs no host decision -- prepare the queries,
+// sample the thresholds, filter GEMM, finalize -- then the two counters (queries to retry / to scan exactly) start their
+// way to pinned host memory and an event marks that point.  Nothing here blocks the host.
+int batch_front(mirx_index *ix, const float *qb, int64_t nb, int k, const int64_t *exb, float *ovb, double *ofb,
+                int64_t *oib, bool tier1, hipStream_t st) {
+    const int bn = gemm_query_tile(nb);
+    const int64_t nb_pad = round_up(nb, bn);
+    ix->pend.active = false;
+    MIRX_HIP(ix->q32p.ensure((size_t)nb_pad * ix->dimp * sizeof(float)));
+    MIRX_HIP(ix->q16.ensure((size_t)nb_pad * ix->dimp * sizeof(uint16_t)));
+    MIRX_HIP(ix->qnorm.ensure((size_t)nb_pad * sizeof(float)));
+    {
+        StageTimer t(ix, st, MIRX_STAGE_PREP);
+        MIRX_HIP(launch_prep_queries(qb, nb, nb_pad, ix->dim, ix->dimp, ix->q32p.as<float>(),
+                                     ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
+    }
+    if (!tier1) {
+        // (an empty gallery lands here too: every slot becomes (-1, -inf))
+        StageTimer t(ix, st, MIRX_STAGE_EXACT);
+        int rc = exact_pass(ix, ix->q32p.as<float>(), nullptr, nb, k, exb, ofb, oib, ovb, st);
+        if (rc) return rc;
+        ix->stats_host.exact_answered += nb;
+        return MIRX_OK;
+    }
+
+    // ---- tier 1 ---------------------------------------------------------------------
+    MIRX_HIP(ix->tau.ensure((size_t)nb_pad * sizeof(float)));
+    int regions = 0, slots = 0;
+    gemm_plan(ix->size, nb_pad, bn, &regions, &slots);
+    MIRX_HIP(ix->cnt.ensure((size_t)nb_pad * regions * sizeof(int)));
+    MIRX_HIP(ix->cand.ensure((size_t)nb_pad * regions * slots * sizeof(Cand)));
+    MIRX_HIP(ix->ovf_cnt.ensure((size_t)nb_pad * sizeof(int)));
+    MIRX_HIP(ix->ovf.ensure((size_t)nb_pad * CAND_OVF * sizeof(Cand)));
+    MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
+    MIRX_HIP(ix->retry_list.ensure((size_t)nb_pad * sizeof(int32_t)));
+    MIRX_HIP(ix->tau2.ensure((size_t)nb_pad * sizeof(float)));
+    GemmArgs ga{};
+    ga.g16 = ix->g16;
+    ga.q16 = ix->q16.as<uint16_t>();
+    ga.gbias = ix->metric == MIRX_METRIC_NEG_L2 ? ix->gbias : nullptr;
+    ga.nq_pad = nb_pad;
+    ga.dimp = ix->dimp;
+    ga.tau = ix->tau.as<float>();
+    ga.regions = regions;
+    ga.slots = slots;
+    ga.region_cnt = ix->cnt.as<int>();
+    ga.cand = ix->cand.as<Cand>();
+    ga.ovf_cnt = ix->ovf_cnt.as<int>();
+    ga.ovf = ix->ovf.as<Cand>();
+    if (ix->force_tau_bits != 0x7fc00000u) {
+        // test hook: one fixed threshold for every query
+        std::vector<float> t((size_t)nb_pad, INFINITY);
+        float v;
+        std::memcpy(&v, &ix->force_tau_bits, 4);
+        std::fill(t.begin(), t.begin() + nb, v);
+        MIRX_HIP(hipMemcpyAsync(ix->tau.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        MIRX_HIP(hipStreamSynchronize(st));
+    } else {
+        // sample = every `stride`-th row, about size/32 rows, a multiple of the 256-row tile; at most
+        // 16384 group maxima per query (the selection sorts them in LDS).  The threshold is the j-th
+        // largest sampled group maximum with j ~ 256 / stride, i.e. about 256 expected candidates per
+        // query whatever the gallery size (j = sample_rank = 8 at the usual stride of 32).
+        const int gpt = gemm_groups_per_tile(bn);
+        int64_t ms = round_up(std::max<int64_t>(ix->size / 32, 4096), ROW_ALIGN);
+        ms = std::min<int64_t>(ms, (int64_t)(16384 / gpt) * ROW_ALIGN);
+        const int64_t stride = std::max<int64_t>(ix->size / ms, 1);
+        const int ngroups = (int)(ms / ROW_ALIGN) * gpt;
+        const int rank_j = (int)std::max<int64_t>(1, std::min<int64_t>(ix->sample_rank, (32 * (int64_t)ix->sample_rank) / stride));
+        MIRX_HIP(ix->groupmax.ensure((size_t)nb_pad * ngroups * sizeof(float)));
+        GemmArgs gs = ga;
+        gs.n_rows = ms;
+        gs.row_stride = stride;
+        gs.groupmax = ix->groupmax.as<float>();
+        gs.ngroups = ngroups;
+        StageTimer t(ix, st, MIRX_STAGE_SAMPLE);
+        MIRX_HIP(launch_gemm_groupmax(gs, bn, st));
+        MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, rank_j, ix->tau.as<float>(), st));
+    }
+    MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * regions * sizeof(int), st));
+    MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
+    MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, 2 * sizeof(int), st));
+    ga.n_rows = ix->size;
+    ga.row_stride = 1;
+    {
+        StageTimer t(ix, st, MIRX_STAGE_GEMM);
+        MIRX_HIP(launch_gemm_filter(ga, bn, st));
+    }
+
+    FinalizeArgs fa{};
+    fa.q32p = ix->q32p.as<float>();
+    fa.qnorm = ix->qnorm.as<float>();
+    fa.g32 = ix->g32;
+    fa.ids = ix->ids;
+    fa.gnorm_max_bits = ix->gnorm_max_bits;
+    fa.tau = ix->tau.as<float>();
+    fa.regions = regions;
+    fa.slots = slots;
+    fa.region_cnt = ix->cnt.as<int>();
+    fa.cand = ix->cand.as<Cand>();
+    fa.ovf_cnt = ix->ovf_cnt.as<int>();
+    fa.ovf = ix->ovf.as<Cand>();
+    fa.exclude = exb;
+    fa.n_rows = ix->size;
+    fa.dimp = ix->dimp;
+    fa.k = k;
+    fa.metric = ix->metric;
+    fa.nq = (int)nb;
+    fa.out_f64 = ofb;
+    fa.out_ids = oib;
+    fa.out_val = ovb;
+    fa.fail_list = ix->fail_list.as<int32_t>();
+    fa.fail_count = ix->fail_count;
+    fa.retry_list = ix->retry_list.as<int32_t>();
+    fa.tau2 = ix->tau2.as<float>();
+    fa.qmap = nullptr;
+    fa.stats = ix->stats_dev;
+    {
+        StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
+        MIRX_HIP(launch_finalize(fa, st));
+    }
+    MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!ix->pend_ev) MIRX_HIP(hipEventCreateWithFlags(&ix->pend_ev, hipEventDisableTiming));
+    MIRX_HIP(hipEventRecord(ix->pend_ev, st));
+    ix->pend.active = true;
+    ix->pend.nb = nb;
+    ix->pend.k = k;
+    ix->pend.exb = exb;
+    ix->pend.ofb = ofb;
+    ix->pend.oib = oib;
+    ix->pend.ovb = ovb;
+    ix->pend.st = st;
+    ix->pend.ga = ga;
+    ix->pend.fa = fa;
+    return MIRX_OK;
+}
+
+// Second half: wait (host only, on the event -- the stream is not drained) for the two counters and run what they ask for:
+// the second-chance filter for queries whose threshold was too high, the exact scan for what is still unanswered.  On the
+// bench workload both counters are zero and this returns after the event.
+int batch_back(mirx_index *ix) {
+    if (!ix->pend.active) return MIRX_OK;
+    ix->pend.active = false;
+    hipStream_t st = ix->pend.st;
+    const GemmArgs &ga = ix->pend.ga;
+    const FinalizeArgs &fa = ix->pend.fa;
+    const int k = ix->pend.k;
+    MIRX_HIP(hipEventSynchronize(ix->pend_ev));
+    const int nretry = ix->fail_count_host[1];
+    if (nretry > 0) {
+        // second chance: same filter GEMM over the gathered queries with tau2 = kth(s~) - 2*eps
+        const int bn2 = gemm_query_tile(nretry);
+        const int64_t nr_pad = round_up(nretry, bn2);
+        int regions2 = 0, slots2 = 0;
+        gemm_plan(ix->size, nr_pad, bn2, &regions2, &slots2);
+        MIRX_HIP(ix->q16r.ensure((size_t)nr_pad * ix->dimp * sizeof(uint16_t)));
+        MIRX_HIP(ix->taur.ensure((size_t)nr_pad * sizeof(float)));
+        MIRX_HIP(ix->cnt.ensure((size_t)nr_pad * regions2 * sizeof(int)));
+        MIRX_HIP(ix->cand.ensure((size_t)nr_pad * regions2 * slots2 * sizeof(Cand)));
+        MIRX_HIP(launch_gather_queries(ix->q16.as<uint16_t>(), ix->tau2.as<float>(), ix->retry_list.as<int32_t>(),
+                                       nretry, nr_pad, ix->dimp, ix->q16r.as<uint16_t>(), ix->taur.as<float>(),
+                                       st));
+        MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nr_pad * regions2 * sizeof(int), st));
+        MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nr_pad * sizeof(int), st));
+        GemmArgs g2 = ga;
+        g2.q16 = ix->q16r.as<uint16_t>();
+        g2.nq_pad = nr_pad;
+        g2.tau = ix->taur.as<float>();
+        g2.regions = regions2;
+        g2.slots = slots2;
+        g2.region_cnt = ix->cnt.as<int>();
+        g2.cand = ix->cand.as<Cand>();
+        {
+            StageTimer t(ix, st, MIRX_STAGE_GEMM);
+            MIRX_HIP(launch_gemm_filter(g2, bn2, st));
+        }
+        FinalizeArgs f2 = fa;
+        f2.tau = ix->taur.as<float>();
+        f2.regions = regions2;
+        f2.slots = slots2;
+        f2.region_cnt = ix->cnt.as<int>();
+        f2.cand = ix->cand.as<Cand>();
+        f2.nq = nretry;
+        f2.retry_list = nullptr;          // no third chance: what fails now goes to the exact scan
+        f2.tau2 = nullptr;
+        f2.qmap = ix->retry_list.as<int32_t>();
+        {
+            StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
+            MIRX_HIP(launch_finalize(f2, st));
+        }
+        MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        MIRX_HIP(hipEventRecord(ix->pend_ev, st));
+        MIRX_HIP(hipEventSynchronize(ix->pend_ev));
+    }
+    const int nfail = ix->fail_count_host[0];
+    if (nfail > 0) {
+        StageTimer t(ix, st, MIRX_STAGE_EXACT);
+        int rc = exact_pass(ix, ix->q32p.as<float>(), ix->fail_list.as<int32_t>(), nfail, k, ix->pend.exb, ix->pend.ofb,
+                            ix->pend.oib, ix->pend.ovb, st);
+        if (rc) return rc;
+        ix->stats_host.exact_answered += nfail;
+    }
+    return MIRX_OK;
+}
+
+// wait_last = false: the last internal batch is left pending (mirx_index_search_begin); batch_back completes it.
 int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude,
-                float *out_val, double *out_f64_user, int64_t *out_ids, hipStream_t st) {
+                float *out_val, double *out_f64_user, int64_t *out_ids, hipStream_t st, bool wait_last = true) {
     MIRX_CHECK(ix, "search: null index");
+    MIRX_CHECK(!ix->pend.active, "search: a search begun with mirx_index_search_begin is still pending (call mirx_index_search_end)");
     MIRX_CHECK(k >= 1 && k <= MAX_K, "search: k must be in [1, 1024]");
     MIRX_CHECK(nq >= 0, "search: nq < 0");
     MIRX_CHECK(nq == 0 || (q && out_ids && (out_val || out_f64_user)), "search: null buffer");
@@ -229,8 +449,6 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
                        k + (exclude ? 1 : 0) <= TIER1_MAX_K;
     for (int64_t q0 = 0; q0 < nq; q0 += QUERY_BATCH) {
         const int64_t nb = std::min<int64_t>(QUERY_BATCH, nq - q0);
-        const int bn = gemm_query_tile(nb);
-        const int64_t nb_pad = round_up(nb, bn);
         const float *qb = q + q0 * ix->dim;
         const int64_t *exb = exclude ? exclude + q0 : nullptr;
         float *ovb = out_val ? out_val + q0 * k : nullptr;
@@ -243,173 +461,11 @@ int search_impl(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t
             MIRX_HIP(ix->stage.ensure((size_t)nb * k * sizeof(double)));
             ofb = ix->stage.as<double>();
         }
-
-        MIRX_HIP(ix->q32p.ensure((size_t)nb_pad * ix->dimp * sizeof(float)));
-        MIRX_HIP(ix->q16.ensure((size_t)nb_pad * ix->dimp * sizeof(uint16_t)));
-        MIRX_HIP(ix->qnorm.ensure((size_t)nb_pad * sizeof(float)));
-        {
-            StageTimer t(ix, st, MIRX_STAGE_PREP);
-            MIRX_HIP(launch_prep_queries(qb, nb, nb_pad, ix->dim, ix->dimp, ix->q32p.as<float>(),
-                                         ix->q16.as<uint16_t>(), ix->qnorm.as<float>(), st));
-        }
-        if (!tier1) {
-            // (an empty gallery lands here too: every slot becomes (-1, -inf))
-            StageTimer t(ix, st, MIRX_STAGE_EXACT);
-            int rc = exact_pass(ix, ix->q32p.as<float>(), nullptr, nb, k, exb, ofb, oib, ovb, st);
+        int rc = batch_front(ix, qb, nb, k, exb, ovb, ofb, oib, tier1, st);
+        if (rc) return rc;
+        if (wait_last || q0 + QUERY_BATCH < nq) {
+            rc = batch_back(ix);
             if (rc) return rc;
-            ix->stats_host.exact_answered += nb;
-            continue;
-        }
-
-        // ---- tier 1 ---------------------------------------------------------------------
-        MIRX_HIP(ix->tau.ensure((size_t)nb_pad * sizeof(float)));
-        int regions = 0, slots = 0;
-        gemm_plan(ix->size, nb_pad, bn, &regions, &slots);
-        MIRX_HIP(ix->cnt.ensure((size_t)nb_pad * regions * sizeof(int)));
-        MIRX_HIP(ix->cand.ensure((size_t)nb_pad * regions * slots * sizeof(Cand)));
-        MIRX_HIP(ix->ovf_cnt.ensure((size_t)nb_pad * sizeof(int)));
-        MIRX_HIP(ix->ovf.ensure((size_t)nb_pad * CAND_OVF * sizeof(Cand)));
-        MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
-        MIRX_HIP(ix->retry_list.ensure((size_t)nb_pad * sizeof(int32_t)));
-        MIRX_HIP(ix->tau2.ensure((size_t)nb_pad * sizeof(float)));
-        GemmArgs ga{};
-        ga.g16 = ix->g16;
-        ga.q16 = ix->q16.as<uint16_t>();
-        ga.gbias = ix->metric == MIRX_METRIC_NEG_L2 ? ix->gbias : nullptr;
-        ga.nq_pad = nb_pad;
-        ga.dimp = ix->dimp;
-        ga.tau = ix->tau.as<float>();
-        ga.regions = regions;
-        ga.slots = slots;
-        ga.region_cnt = ix->cnt.as<int>();
-        ga.cand = ix->cand.as<Cand>();
-        ga.ovf_cnt = ix->ovf_cnt.as<int>();
-        ga.ovf = ix->ovf.as<Cand>();
-        if (ix->force_tau_bits != 0x7fc00000u) {
-            // test hook: one fixed threshold for every query
-            std::vector<float> t((size_t)nb_pad, INFINITY);
-            float v;
-            std::memcpy(&v, &ix->force_tau_bits, 4);
-            std::fill(t.begin(), t.begin() + nb, v);
-            MIRX_HIP(hipMemcpyAsync(ix->tau.p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, st));
-            MIRX_HIP(hipStreamSynchronize(st));
-        } else {
-            // sample = every `stride`-th row, about size/32 rows, a multiple of the 256-row tile; at most
-            // 16384 group maxima per query (the selection sorts them in LDS).  The threshold is the j-th
-            // largest sampled group maximum with j ~ 256 / stride, i.e. about 256 expected candidates per
-            // query whatever the gallery size (j = sample_rank = 8 at the usual stride of 32).
-            const int gpt = gemm_groups_per_tile(bn);
-            int64_t ms = round_up(std::max<int64_t>(ix->size / 32, 4096), ROW_ALIGN);
-            ms = std::min<int64_t>(ms, (int64_t)(16384 / gpt) * ROW_ALIGN);
-            const int64_t stride = std::max<int64_t>(ix->size / ms, 1);
-            const int ngroups = (int)(ms / ROW_ALIGN) * gpt;
-            const int rank_j = (int)std::max<int64_t>(1, std::min<int64_t>(ix->sample_rank, (32 * (int64_t)ix->sample_rank) / stride));
-            MIRX_HIP(ix->groupmax.ensure((size_t)nb_pad * ngroups * sizeof(float)));
-            GemmArgs gs = ga;
-            gs.n_rows = ms;
-            gs.row_stride = stride;
-            gs.groupmax = ix->groupmax.as<float>();
-            gs.ngroups = ngroups;
-            StageTimer t(ix, st, MIRX_STAGE_SAMPLE);
-            MIRX_HIP(launch_gemm_groupmax(gs, bn, st));
-            MIRX_HIP(launch_select_tau(ix->groupmax.as<float>(), ngroups, nb, nb_pad, rank_j, ix->tau.as<float>(), st));
-        }
-        MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nb_pad * regions * sizeof(int), st));
-        MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nb_pad * sizeof(int), st));
-        MIRX_HIP(hipMemsetAsync(ix->fail_count, 0, 2 * sizeof(int), st));
-        ga.n_rows = ix->size;
-        ga.row_stride = 1;
-        {
-            StageTimer t(ix, st, MIRX_STAGE_GEMM);
-            MIRX_HIP(launch_gemm_filter(ga, bn, st));
-        }
-
-        FinalizeArgs fa{};
-        fa.q32p = ix->q32p.as<float>();
-        fa.qnorm = ix->qnorm.as<float>();
-        fa.g32 = ix->g32;
-        fa.ids = ix->ids;
-        fa.gnorm_max_bits = ix->gnorm_max_bits;
-        fa.tau = ix->tau.as<float>();
-        fa.regions = regions;
-        fa.slots = slots;
-        fa.region_cnt = ix->cnt.as<int>();
-        fa.cand = ix->cand.as<Cand>();
-        fa.ovf_cnt = ix->ovf_cnt.as<int>();
-        fa.ovf = ix->ovf.as<Cand>();
-        fa.exclude = exb;
-        fa.n_rows = ix->size;
-        fa.dimp = ix->dimp;
-        fa.k = k;
-        fa.metric = ix->metric;
-        fa.nq = (int)nb;
-        fa.out_f64 = ofb;
-        fa.out_ids = oib;
-        fa.out_val = ovb;
-        fa.fail_list = ix->fail_list.as<int32_t>();
-        fa.fail_count = ix->fail_count;
-        fa.retry_list = ix->retry_list.as<int32_t>();
-        fa.tau2 = ix->tau2.as<float>();
-        fa.qmap = nullptr;
-        fa.stats = ix->stats_dev;
-        {
-            StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
-            MIRX_HIP(launch_finalize(fa, st));
-        }
-        MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        MIRX_HIP(hipStreamSynchronize(st));
-        const int nretry = ix->fail_count_host[1];
-        if (nretry > 0) {
-            // second chance: same filter GEMM over the gathered queries with tau2 = kth(s~) - 2*eps
-            const int bn2 = gemm_query_tile(nretry);
-            const int64_t nr_pad = round_up(nretry, bn2);
-            int regions2 = 0, slots2 = 0;
-            gemm_plan(ix->size, nr_pad, bn2, &regions2, &slots2);
-            MIRX_HIP(ix->q16r.ensure((size_t)nr_pad * ix->dimp * sizeof(uint16_t)));
-            MIRX_HIP(ix->taur.ensure((size_t)nr_pad * sizeof(float)));
-            MIRX_HIP(ix->cnt.ensure((size_t)nr_pad * regions2 * sizeof(int)));
-            MIRX_HIP(ix->cand.ensure((size_t)nr_pad * regions2 * slots2 * sizeof(Cand)));
-            MIRX_HIP(launch_gather_queries(ix->q16.as<uint16_t>(), ix->tau2.as<float>(), ix->retry_list.as<int32_t>(),
-                                           nretry, nr_pad, ix->dimp, ix->q16r.as<uint16_t>(), ix->taur.as<float>(),
-                                           st));
-            MIRX_HIP(hipMemsetAsync(ix->cnt.p, 0, (size_t)nr_pad * regions2 * sizeof(int), st));
-            MIRX_HIP(hipMemsetAsync(ix->ovf_cnt.p, 0, (size_t)nr_pad * sizeof(int), st));
-            GemmArgs g2 = ga;
-            g2.q16 = ix->q16r.as<uint16_t>();
-            g2.nq_pad = nr_pad;
-            g2.tau = ix->taur.as<float>();
-            g2.regions = regions2;
-            g2.slots = slots2;
-            g2.region_cnt = ix->cnt.as<int>();
-            g2.cand = ix->cand.as<Cand>();
-            {
-                StageTimer t(ix, st, MIRX_STAGE_GEMM);
-                MIRX_HIP(launch_gemm_filter(g2, bn2, st));
-            }
-            FinalizeArgs f2 = fa;
-            f2.tau = ix->taur.as<float>();
-            f2.regions = regions2;
-            f2.slots = slots2;
-            f2.region_cnt = ix->cnt.as<int>();
-            f2.cand = ix->cand.as<Cand>();
-            f2.nq = nretry;
-            f2.retry_list = nullptr;          // no third chance: what fails now goes to the exact scan
-            f2.tau2 = nullptr;
-            f2.qmap = ix->retry_list.as<int32_t>();
-            {
-                StageTimer t(ix, st, MIRX_STAGE_FINALIZE);
-                MIRX_HIP(launch_finalize(f2, st));
-            }
-            MIRX_HIP(hipMemcpyAsync(ix->fail_count_host, ix->fail_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-            MIRX_HIP(hipStreamSynchronize(st));
-        }
-        const int nfail = ix->fail_count_host[0];
-        if (nfail > 0) {
-            StageTimer t(ix, st, MIRX_STAGE_EXACT);
-            int rc = exact_pass(ix, ix->q32p.as<float>(), ix->fail_list.as<int32_t>(), nfail, k, exb, ofb,
-                                oib, ovb, st);
-            if (rc) return rc;
-            ix->stats_host.exact_answered += nfail;
         }
     }
     return MIRX_OK;
@@ -464,6 +520,7 @@ void mirx_index_destroy(mirx_index *ix) {
     if (ix->stats_dev) (void)hipFree(ix->stats_dev);
     if (ix->fail_count_host) (void)hipHostFree(ix->fail_count_host);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    if (ix->pend_ev) (void)hipEventDestroy(ix->pend_ev);
     for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->ovf_cnt, &ix->ovf, &ix->groupmax,
                       &ix->fail_list, &ix->retry_list, &ix->tau2, &ix->q16r, &ix->taur, &ix->scores, &ix->stage,
                       &ix->rankwork})
@@ -562,6 +619,19 @@ int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
                           void *stream) {
     return search_impl(ix, q, nq, k, exclude_ids_or_null, nullptr, out_rank_scores, out_ids,
                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int mirx_index_search_begin(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude_ids_or_null,
+                            float *out_scores_or_null, double *out_rank_scores_or_null, int64_t *out_ids, void *stream) {
+    return search_impl(ix, q, nq, k, exclude_ids_or_null, out_scores_or_null, out_rank_scores_or_null, out_ids,
+                       reinterpret_cast<hipStream_t>(stream), /*wait_last=*/false);
+}
+
+int mirx_index_search_end(mirx_index *ix) {
+    MIRX_CHECK(ix, "search_end: null index");
+    DeviceGuard dg(ix->device);
+    if (!dg.ok) return fail(MIRX_EHIP, "search_end: cannot select the index device");
+    return batch_back(ix);
 }
 
 int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out) {

@@ -6,7 +6,8 @@ contiguous gallery rows [r*N/W, (r+1)*N/W) with GLOBAL ids.  A search is:
   1. every rank embeds its own queries (plain data-parallel replicas, no collective),
   2. all-gather of the query embeddings  [Q_local, D] fp32  ->  [W*Q_local, D],
   3. local exact top-k of ALL queries against the local shard (libmirx),
-  4. ONE all-gather of the packed per-shard candidates (fp64 ranking score, int64 id) [Q, k],
+  4. ONE all-gather of the packed per-shard candidates (fp64 ranking score, int64 id) [Q, k]
+     (optionally in pieces, each launched asynchronously behind its local search: `chunks`),
   5. k-way merge of this rank's own queries (score desc, id asc) -- exact, because the top-k
      of a union is contained in the union of the per-shard top-k lists.
 
@@ -57,21 +58,63 @@ class ShardedSearcher:
         dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
         return out
 
-    def search(self, q_local, k):
+    def search(self, q_local, k, chunks=1, events=None):
         """Top-k over the WHOLE gallery for this rank's queries.
 
         -> (fp64 ranking scores [Q_local,k], reported fp32 values [Q_local,k], ids [Q_local,k])
-        Every rank must call with the same Q_local and k."""
+        Every rank must call with the same Q_local, k and chunks.
+
+        chunks > 1: every rank's queries are cut into `chunks` equal pieces; piece c of ALL ranks is searched locally and its
+        candidate all-gather is launched asynchronously, so that it overlaps the local search of piece c + 1 (the collective
+        runs on the backend's own stream; the search kernels stay on the current stream).
+        events: optional dict that receives torch.cuda.Event pairs per stage ("gather_q", "search", "gather_cand", "merge")
+        for the caller's stage timing (CUDA tensors only)."""
         w, r = self.world_size, self.rank
         ql = q_local.shape[0]
+
+        def mark(name, begin):
+            if events is not None and q_local.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                events.setdefault(name, []).append((begin, ev))
+
+        mark("gather_q", True)
         q_all = self.gather_queries(q_local)
-        s_loc, i_loc = self.local_search(q_all, k)
+        mark("gather_q", False)
         if w == 1:
-            return self.merge(s_loc[None], i_loc[None], self.metric)
-        # one packed all-gather: [Q, k] x (score, id) as 2 x int64 words
-        packed = torch.stack([s_loc.contiguous().view(torch.int64), i_loc.contiguous()], 0)
-        flat = packed.new_empty(w * packed.numel())
-        dist.all_gather_into_tensor(flat, packed.view(-1), group=self.group)
-        gathered = flat.view((w,) + tuple(packed.shape))
-        mine = gathered[:, :, r * ql:(r + 1) * ql, :].contiguous()        # [W, 2, Ql, k]
-        return self.merge(mine[:, 0].contiguous().view(torch.float64), mine[:, 1].contiguous(), self.metric)
+            mark("search", True)
+            s_loc, i_loc = self.local_search(q_all, k)
+            mark("search", False)
+            mark("merge", True)
+            out = self.merge(s_loc[None], i_loc[None], self.metric)
+            mark("merge", False)
+            return out
+        if chunks < 1 or ql % chunks:
+            raise ValueError("chunks must divide the per-rank query count")
+        qc = ql // chunks
+        blocks = q_all.view(w, ql, q_all.shape[1])
+        pending = []
+        for c in range(chunks):
+            qa = q_all if chunks == 1 else blocks[:, c * qc:(c + 1) * qc].reshape(w * qc, q_all.shape[1])
+            mark("search", True)
+            s_loc, i_loc = self.local_search(qa, k)
+            mark("search", False)
+            # one packed all-gather per piece: [Q, k] x (score, id) as 2 x int64 words
+            packed = torch.stack([s_loc.contiguous().view(torch.int64), i_loc.contiguous()], 0)
+            flat = packed.new_empty(w * packed.numel())
+            mark("gather_cand", True)
+            work = dist.all_gather_into_tensor(flat, packed.view(-1), group=self.group, async_op=chunks > 1)
+            mark("gather_cand", False)
+            pending.append((work, flat, tuple(packed.shape)))
+        outs = []
+        for work, flat, shape in pending:
+            if work is not None:
+                work.wait()
+            gathered = flat.view((w,) + shape)
+            mine = gathered[:, :, r * qc:(r + 1) * qc, :].contiguous()        # [W, 2, qc, k]
+            mark("merge", True)
+            outs.append(self.merge(mine[:, 0].contiguous().view(torch.float64), mine[:, 1].contiguous(), self.metric))
+            mark("merge", False)
+        if len(outs) == 1:
+            return outs[0]
+        return tuple(None if outs[0][j] is None else torch.cat([o[j] for o in outs], 0) for j in range(3))

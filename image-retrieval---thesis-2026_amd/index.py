@@ -128,6 +128,29 @@ class FlatIndex:
         _lib.check(rc, "mirx_index_search")
         return sc, ids
 
+    def search_begin(self, q, k, exclude_ids=None):
+        """First half of search(): enqueue the whole first pass on the current stream and return without waiting.
+        -> a handle for search_end(); the index must not be used for anything else in between."""
+        q, ex = self._prep_queries(q, exclude_ids)
+        nq = q.shape[0]
+        ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        s64 = torch.empty((nq, k), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.mirx_index_search_begin(self._h, ctypes.c_void_p(q.data_ptr()), nq, int(k),
+                                                         ctypes.c_void_p(ex.data_ptr()) if ex is not None else None,
+                                                         ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(s64.data_ptr()),
+                                                         ctypes.c_void_p(ids.data_ptr()), _stream_ptr(self.device)),
+                       "mirx_index_search_begin")
+        return (q, ex, sc, s64, ids)                         # keeps the buffers alive until search_end
+
+    def search_end(self, handle, return_f64=False):
+        """Second half: wait for the first pass's counters (host wait on an event), run the rare follow-up passes.
+        -> (scores, ids) like search()."""
+        _lib.check(self._lib.mirx_index_search_end(self._h), "mirx_index_search_end")
+        _, _, sc, s64, ids = handle
+        return (s64 if return_f64 else sc), ids
+
     def rank_all(self, q, exclude_ids=None, with_scores=False):
         """Full ranking [nq, ntotal] (row = query, excluded id last)."""
         q, ex = self._prep_queries(q, exclude_ids)

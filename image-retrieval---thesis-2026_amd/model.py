@@ -480,11 +480,14 @@ def _linear_out_bound(ln, lin, rows=None):
     ||LN(x)||_2 <= max|gamma| sqrt(C) + ||beta||_2 (the normalised vector has squared norm C), so
     |y_j| <= that * ||W_j||_2 + |b_j|.  GELU and softmax-weighted averages of such outputs obey the same bound."""
     g, b = ln.weight, ln.bias
-    key = (None if g is None else g._version, None if b is None else b._version, lin.weight._version, lin.weight.data_ptr(),
-           None if lin.bias is None else lin.bias._version, None if rows is None else (rows.start, rows.stop))
+    ver = (None if g is None else g._version, None if b is None else b._version, lin.weight._version, lin.weight.data_ptr(),
+           None if lin.bias is None else lin.bias._version)
     store = lin.__dict__.setdefault("_mirx_out_bound", {})
-    if key not in store:
+    if store.get("ver") != ver:                      # weights changed: every cached row range is stale
         store.clear()
+        store["ver"] = ver
+    key = None if rows is None else (rows.start, rows.stop)
+    if key not in store:
         c = ln.normalized_shape[-1]
         gm = 1.0 if g is None else float(g.detach().abs().max())
         bn = 0.0 if b is None else float(torch.linalg.vector_norm(b.detach().double()))

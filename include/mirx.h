@@ -125,6 +125,23 @@ int mirx_index_search_f64(mirx_index *ix, const float *q, int64_t nq, int k,
                           const int64_t *exclude_ids_or_null, double *out_rank_scores,
                           int64_t *out_ids, void *stream);
 
+/*
+ * The same search in two calls, so that the host does not block while the first pass runs (the caller may enqueue the next
+ * embed micro-batch, on this or another stream, between them):
+ *   mirx_index_search_begin  enqueues query preparation, threshold sampling, the filter GEMM and finalize on `stream` and
+ *       returns; the two counters that say whether any query needs the second-chance filter or the exact scan travel to
+ *       pinned host memory behind an event.  Either output form may be NULL (not both).
+ *   mirx_index_search_end    waits for that event (a host wait; the stream is not drained), runs the rare follow-up passes
+ *       the counters ask for on the same stream, and returns.  The outputs are complete when work enqueued on the stream
+ *       up to this call has finished; stats / timings refer to this search.
+ * Between the two calls the index must not be searched, ranked or extended, and the query / output buffers must stay valid.
+ * mirx_index_search == begin + end.  (No reference counterpart: MilvusRetriever.search is a blocking RPC,
+ * milvus/milvus_retrieval.py:80-86.)
+ */
+int mirx_index_search_begin(mirx_index *ix, const float *q, int64_t nq, int k, const int64_t *exclude_ids_or_null,
+                            float *out_scores_or_null, double *out_rank_scores_or_null, int64_t *out_ids, void *stream);
+int mirx_index_search_end(mirx_index *ix);
+
 /* Waits for `stream`, then copies the counters of the last search. */
 int mirx_index_last_stats(mirx_index *ix, void *stream, mirx_search_stats *out);
 

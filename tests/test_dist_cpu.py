@@ -31,7 +31,7 @@ def _np_merge(scores, ids, metric):
     return torch.from_numpy(out_s), None, torch.from_numpy(out_i)
 
 
-def _worker(rank, world, port, n, d, ql, k, ret):
+def _worker(rank, world, port, n, d, ql, k, ret, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -45,7 +45,7 @@ def _worker(rank, world, port, n, d, ql, k, ret):
             return torch.from_numpy(s), torch.from_numpy(i)
 
         ss = ShardedSearcher(local, "COSINE", merge=_np_merge)
-        s, _, i = ss.search(q[rank * ql:(rank + 1) * ql], k)
+        s, _, i = ss.search(q[rank * ql:(rank + 1) * ql], k, chunks=chunks)
         ret[rank] = (s.numpy(), i.numpy())
     finally:
         dist.destroy_process_group()
@@ -65,6 +65,23 @@ def test_sharded_search_world2_equals_global_oracle():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, d, ql, k, ret), nprocs=world, join=True)
+    g = torch.nn.functional.normalize(torch.randn(n, d, generator=torch.Generator().manual_seed(1)), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(world * ql, d, generator=torch.Generator().manual_seed(2)), dim=1)
+    o_s, o_i = OS.topk(q.numpy(), g.numpy(), k)
+    for r in range(world):
+        s, i = ret[r]
+        np.testing.assert_array_equal(i, o_i[r * ql:(r + 1) * ql])
+        np.testing.assert_array_equal(s, o_s[r * ql:(r + 1) * ql])
+
+
+@pytest.mark.parametrize("chunks", [2, 4])
+def test_sharded_search_in_pieces_with_async_gathers(chunks):
+    """chunks > 1: piece c of every rank's queries is searched while the candidate all-gather of piece c - 1 is in
+    flight; the result must not depend on the cut."""
+    n, d, ql, k, world = 1500, 16, 8, 5, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, d, ql, k, ret, chunks), nprocs=world, join=True)
     g = torch.nn.functional.normalize(torch.randn(n, d, generator=torch.Generator().manual_seed(1)), dim=1)
     q = torch.nn.functional.normalize(torch.randn(world * ql, d, generator=torch.Generator().manual_seed(2)), dim=1)
     o_s, o_i = OS.topk(q.numpy(), g.numpy(), k)

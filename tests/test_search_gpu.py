@@ -193,3 +193,82 @@ def test_clustered_gallery_second_chance_pass(metric):
     st = ix.last_stats()
     assert st["incomplete"] > 0, st                       # the first pass did reject queries ...
     assert st["tier1_answered"] >= nq * 0.9, st           # ... and the second pass answered them
+
+
+@pytest.mark.parametrize("nq", [40, 100, 300])
+def test_adjacent_passing_rows_claim_distinct_candidate_slots(nq):
+    """the per-region fill counters of the filter GEMM are shared by the lanes that hold the same query
+    (2 lanes in k_gemm, 4 in k_gemm16).  A gallery of 200-row runs of identical vectors and a forced mid-range threshold
+    make MANY adjacent rows of one query pass in the same accumulator tile: every one of them must get its own slot --
+    stats.candidates equals the exact number of passing rows (no overflow, no loss), and the answer is the oracle's
+    (ties -> lowest ids)."""
+    from mirx import _lib as L
+    from mirx.index import FlatIndex
+    d, run, nbase = 256, 200, 200
+    n = run * nbase
+    base = _unit(nbase, d, 21)
+    g = base.repeat_interleave(run, dim=0)                    # rows 200 i .. 200 i + 199 are copies of base[i]
+    qi = torch.arange(nq) % nbase
+    q = base[qi]
+    ix = FlatIndex(d, "COSINE", 0)
+    ix.add(g)
+    dots = (base @ base.t()).fill_diagonal_(-1)
+    assert float(dots.max()) < 0.45                            # every other base is far below the threshold
+    ix.set_option(L.OPT_FORCE_TAU, int(np.float32(0.5).view(np.uint32)))
+    s, i = ix.search(q, 10, return_f64=True)
+    st = ix.last_stats()
+    assert st["candidates"] == nq * run, st                     # exactly the copies of the query's base, each once
+    assert st["overflowed"] == 0 and st["incomplete"] == 0 and st["tier1_answered"] == nq, st
+    o_s, o_i = OS.topk(q.numpy(), g.numpy(), 10)
+    np.testing.assert_array_equal(i.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+    assert np.array_equal(o_i[:, 0], (qi * run).numpy())       # the lowest id of the run
+
+
+def test_more_than_8192_queries_multi_pass():
+    """VERDICT r1 (e): 8192 + 300 queries in one call = two internal passes (8192, then 300 at a different query tile);
+    ids, fp64 scores and the aggregated stats must be those of one search (W = 8 ranks hit this path with 32 768 queries)."""
+    from mirx.index import FlatIndex
+    n, d, nq = 40000, 256, 8192 + 300
+    g, q = _unit(n, d, 31), _unit(nq, d, 32)
+    ix = FlatIndex(d, "COSINE", 0)
+    ix.add(g)
+    s, i = ix.search(q, 10, return_f64=True)
+    st = ix.last_stats()
+    o_s, o_i = OS.topk(q.numpy(), g.numpy(), 10)
+    np.testing.assert_array_equal(i.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+    assert st["nq"] == nq and st["tier1_answered"] + st["exact_answered"] == nq, st
+    ex = np.arange(nq) % n                                      # with exclusions, reported fp32 values
+    s32, i2 = ix.search(q, 10, exclude_ids=ex)
+    o_s2, o_i2 = OS.topk(q.numpy(), g.numpy(), 10, exclude=ex)
+    np.testing.assert_array_equal(i2.cpu().numpy(), o_i2)
+    np.testing.assert_array_equal(s32.cpu().numpy(), OS.reported_value(o_s2, 0).astype(np.float32))
+
+
+def test_search_begin_end_equals_search():
+    """mirx_index_search_begin / _end: the first pass is enqueued without blocking the host, other work may be queued in
+    between, the result equals the blocking call -- including when the follow-up passes are needed (forced thresholds)."""
+    from mirx import _lib as L
+    from mirx.index import FlatIndex
+    n, d, nq = 50000, 256, 600
+    g, q = _unit(n, d, 41), _unit(nq, d, 42)
+    ix = FlatIndex(d, "COSINE", 0)
+    ix.add(g)
+    o_s, o_i = OS.topk(q.numpy(), g.numpy(), 10)
+    for tau in (None, 0.9, -1.0):                               # normal, every query incomplete, every query overflowed
+        if tau is not None:
+            ix.set_option(L.OPT_FORCE_TAU, int(np.float32(tau).view(np.uint32)))
+        h = ix.search_begin(q, 10)
+        filler = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # queued behind the first pass
+        with pytest.raises(L.MirxError):
+            ix.search(q, 10)                                    # the index is busy until search_end
+        s, i = ix.search_end(h, return_f64=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i.cpu().numpy(), o_i)
+        np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+        s32, i32 = ix.search(q, 10)
+        np.testing.assert_array_equal(i32.cpu().numpy(), o_i)
+        assert filler.shape == (2048, 2048)
+    ix.set_option(L.OPT_FORCE_TAU, L.FORCE_TAU_OFF)
+    assert ix._lib.mirx_index_search_end(ix._h) == 0           # nothing pending: a no-op

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-hip-conv1x1", action="store_true")
     ap.add_argument("--model", default="densenet121", choices=["densenet121", "convnextv2", "dinov2", "medsiglip"])
     ap.add_argument("--no-split3-linear", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (tail overlap)")
     ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
     ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (direct2h | wino)")
     a = ap.parse_args()
@@ -50,13 +51,29 @@ def main():
     if a.channels_last:
         m = m.to(memory_format=torch.channels_last)
     x = torch.randn(a.batch, 3, a.size, a.size, device=dev)
+    streams = [torch.cuda.Stream() for _ in range(a.streams)] if a.streams > 1 else None
+    parts = list(x.chunk(a.streams)) if streams else None
+
+    def fwd():
+        if not streams:
+            return m(x)
+        cur = torch.cuda.current_stream()
+        outs = []
+        for s_, p_ in zip(streams, parts):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                outs.append(m(p_))
+        for s_ in streams:
+            cur.wait_stream(s_)
+        return outs
+
     with torch.no_grad():
         for _ in range(a.warmup):
-            m(x)
+            fwd()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.iters):
-            y = m(x)
+            y = fwd()
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     print(f"B={a.batch} {a.size}x{a.size}: {dt*1e3:.1f} ms/batch, {a.batch/dt:.0f} img/s")
