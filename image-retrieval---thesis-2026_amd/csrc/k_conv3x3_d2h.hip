@@ -19,9 +19,11 @@
 //     is staged and stored pixel-major -- [term][padded pixel][16 channels] fp16, the two 16-byte halves of a pixel
 //     at slot h ^ ((pixel >> 3) & 1) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
 //     ds_read_b128 per term.  Double-buffered, register-prefetched.
-//   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][2 terms][32 oc][16 c] fp16); a lane reads its
-//     16-byte A fragments straight from global memory (147 KiB per layer, L2-resident): taps 0..3 at the end of the
-//     previous stage, taps 4..8 two taps ahead of their use.
+//   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][2 terms][32 oc][16 c] fp16).  The 18 KiB of a
+//     stage go global -> LDS by DMA ONCE per workgroup (18 one-KiB pieces = one (tap, term) plane each, double-buffered,
+//     issued right after the stage barrier) and every wave reads its A fragments from there.  k_conv3x3_d3 lets every
+//     wave fetch its fragments from L2 itself: four times the bytes -- 144 KiB per CU per stage pair, three quarters of
+//     the L2 -> CU bandwidth, which is what bounded this kernel (0.92 ms per 1024-image 56 x 56 layer) before.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -33,6 +35,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 constexpr int CIN = 128, COUT = 32;
 constexpr int KC = 16;                        // channels per stage = one MFMA K
@@ -57,6 +61,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
     constexpr int NPIX = PR * PW;             // padded pixels of a stage
     constexpr int PLANE = NPIX * 32;          // bytes of one term of one stage (32 B per pixel)
     constexpr int STAGE = 2 * PLANE;
+    constexpr int WSTAGE = 9 * 2 * COUT * KC * 2;   // bytes of one stage of weights (18 KiB): 18 pieces of 1 KiB
+    constexpr int W_LDS0 = 2 * STAGE;               // weight buffers behind the two activation buffers
     constexpr int NOUT = R * W;               // output pixels of a full strip
     constexpr int NBLK = (NOUT + 31) / 32;    // 7
     static_assert(NBLK <= 8, "two column blocks per wave");
@@ -126,9 +132,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
         if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
         pbase[t] = (p / W) * PW + (p % W);
     }
-    // A fragments: w3[stage][tap][term][oc = n][16], this lane's 16 bytes at channel 8 half
-    const uint16_t *wp = w3 + (int64_t)n * KC + 8 * half;
-    constexpr int W_TERM = COUT * KC, W_TAP = 2 * W_TERM, W_ST = 9 * W_TAP;
+    // A fragments from LDS: piece (tap, term) = 32 output channels x 32 B; chunk `half` of row n sits at slot
+    // half ^ ((n >> 3) & 1) (conflict-free ds_read_b128, as in k_conv1x1_h2).  DMA: lane l of a wave writes 16 B at
+    // piece base + 16 l = (row l / 2, slot l & 1), which must hold source chunk (l & 1) ^ ((l >> 4) & 1).
+    const int a_off = n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w3, 0, NST * WSTAGE, 0x00020000);
+    const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    auto dma_w = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int piece = wave + 4 * i;               // 18 pieces: waves 0, 1 take five, waves 2, 3 four
+            if (piece < 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + W_LDS0 + buf * WSTAGE + piece * 1024), 16, w_voff,
+                                                         st * WSTAGE + piece * 1024, 0, 0);
+        }
+    };
 
     f32x16 acc[2];
 #pragma unroll
@@ -136,76 +154,77 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Weights.  vmcnt is in order: an MFMA that waits for a weight fragment also waits for every load issued before
-    // it -- including the activation prefetch of the stage (issued at the top, needed only at the end, HBM latency).
-    // So the fragments of taps 0..3 are loaded at the END of the previous stage (older than the prefetch: their
-    // waits cost nothing), and taps 4..8 are loaded two taps ahead of their use: the first wait that drags the
-    // prefetch in comes after four taps (~3000 matrix cycles) of cover.
-    f16x8 wf[9][2];
-#define MIRX_D2H_LOADW(TAP, SRC)                                                                    \
+#define MIRX_D2H_READA(DST, TAP)                                                                   \
     {                                                                                              \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                           \
-            wf[TAP][q_] = *reinterpret_cast<const f16x8 *>((SRC) + (TAP) * W_TAP + q_ * W_TERM);   \
+        DST[0] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP)) * 1024 + a_off);                \
+        DST[1] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP) + 1) * 1024 + a_off);            \
     }
-#pragma unroll
-    for (int tap = 0; tap < 4; ++tap) MIRX_D2H_LOADW(tap, wp)
-
-#define MIRX_D2H_READB(DST, TAP, T)                                                                 \
+#define MIRX_D2H_READB(DST, TAP, T)                                                                \
     {                                                                                              \
         const int pix_ = pbase[T] + ((TAP) / 3) * PW + (TAP) % 3;                                  \
         const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 3) & 1)) << 4);                      \
         DST[0] = *reinterpret_cast<const f16x8 *>(pb_);                                            \
         DST[1] = *reinterpret_cast<const f16x8 *>(pb_ + PLANE);                                    \
     }
-#define MIRX_D2H_MFMA(T, TAP, B)                                                                    \
+#define MIRX_D2H_MFMA(T, A, B)                                                                     \
     {                                                                                              \
         f32x16 c_ = acc[T];                                                                        \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][1], B[0], c_, 0, 0, 0);                \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][0], B[1], c_, 0, 0, 0);                \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[TAP][0], B[0], c_, 0, 0, 0);                \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], c_, 0, 0, 0);                      \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], c_, 0, 0, 0);                      \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], c_, 0, 0, 0);                      \
         acc[T] = c_;                                                                               \
     }
     const bool two = live_blk[1];                          // wave-uniform: waves 0..2 own two column blocks
+    dma_w(0, 0);
     load(0);
     store(0);
     for (int st = 0; st < NST; ++st) {
         const int cur = st & 1;
-        __syncthreads();                                   // stage st visible; buffer cur ^ 1 free
-        load(st + 1 < NST ? st + 1 : st);                  // branch-free: the last stage re-loads itself
+        // stage st visible: activations stored by every wave, and THIS wave's weight DMA landed (vmcnt(0): the compiler's
+        // own wait before s_barrier does not cover the asynchronous LDS writes; no counted wait -- LDS-DMA and loads to
+        // registers do not retire in one common order, see k_conv1x1_h2); buffers cur ^ 1 free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_w(st + 1 < NST ? st + 1 : st, cur ^ 1);        // branch-free: the last stage re-loads itself
+#ifndef MIRX_D2H_EXP_NOLOAD          // diagnostic build: no activation prefetch (results wrong) -> time without HBM latency
+        load(st + 1 < NST ? st + 1 : st);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const char *sb = sm + cur * STAGE;
-        const uint16_t *wc = wp + (int64_t)st * W_ST;
-        const uint16_t *wn = wp + (int64_t)(st + 1 < NST ? st + 1 : st) * W_ST;
-        // B fragments are read one (tap, block) unit ahead of the MFMAs that use them
-        f16x8 b0[2], b1[2];
+        const char *wb = sm + W_LDS0 + cur * WSTAGE;
+        // fragments are read one (tap, block) unit ahead of the MFMAs that use them
+        f16x8 a0[2], a1[2], b0[2], b1[2];
+        MIRX_D2H_READA(a0, 0)
         MIRX_D2H_READB(b0, 0, 0)
         if (two) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                if (tap >= 2 && tap + 2 < 9) MIRX_D2H_LOADW(tap + 2, wc)
                 MIRX_D2H_READB(b1, tap, 1)
+                if (tap + 1 < 9) {
+                    if (tap & 1) { MIRX_D2H_READA(a0, tap + 1) } else { MIRX_D2H_READA(a1, tap + 1) }
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                MIRX_D2H_MFMA(0, tap, b0)
+                if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
                 if (tap + 1 < 9) MIRX_D2H_READB(b0, tap + 1, 0)
                 __builtin_amdgcn_sched_barrier(0);
-                MIRX_D2H_MFMA(1, tap, b1)
+                if (tap & 1) { MIRX_D2H_MFMA(1, a1, b1) } else { MIRX_D2H_MFMA(1, a0, b1) }
             }
         } else {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                if (tap >= 2 && tap + 2 < 9) MIRX_D2H_LOADW(tap + 2, wc)
-                if (tap + 1 < 9) MIRX_D2H_READB(b1, tap + 1, 0)
+                if (tap + 1 < 9) {
+                    MIRX_D2H_READB(b1, tap + 1, 0)
+                    if (tap & 1) { MIRX_D2H_READA(a0, tap + 1) } else { MIRX_D2H_READA(a1, tap + 1) }
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                MIRX_D2H_MFMA(0, tap, b0)
+                if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) b0[q] = b1[q];
             }
         }
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap) MIRX_D2H_LOADW(tap, wn)       // next stage's early taps: older than its prefetch
         store(cur ^ 1);
     }
-#undef MIRX_D2H_LOADW
+#undef MIRX_D2H_READA
 #undef MIRX_D2H_READB
 #undef MIRX_D2H_MFMA
 
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
 template <int W, int R>
 hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
                       const float *in_range, float *out_range, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * (R + 2) * (W + 2) * 32;
+    const size_t lds = (size_t)2 * 2 * (R + 2) * (W + 2) * 32 + 2 * 9 * 2 * 32 * 16 * 2;     // activations + weights, both double-buffered
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2h<W, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

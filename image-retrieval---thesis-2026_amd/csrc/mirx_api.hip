@@ -991,6 +991,25 @@ int mirx_stem_conv7_bn_relu_pool_split3(const float *x, const void *w3, const fl
     return MIRX_OK;
 }
 
+int mirx_range_absmax(const float *x, int64_t n, float *range_slots, void *stream) {
+    MIRX_CHECK(n >= 0 && (n == 0 || (x && range_slots)), "range_absmax: null buffer");
+    MIRX_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0, "range_absmax: x must be 16-byte aligned");
+    MIRX_HIP(launch_range_absmax(x, n, range_slots, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, const float *oscale, const float *scale,
+                                              const float *shift, int64_t n, int h, int wd, float *y, int64_t y_batch_stride,
+                                              const float *in_range, float *out_range_or_null, void *stream) {
+    MIRX_CHECK(x && w2 && oscale && scale && shift && y && in_range && n >= 0 && n <= 65535,
+               "stem_split2h: null argument or batch > 65535");
+    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split2h: H and W must be multiples of 4");
+    MIRX_CHECK(y_batch_stride >= (int64_t)64 * (h / 4) * (wd / 4), "stem_split2h: output batch stride too small");
+    MIRX_HIP(launch_stem_h2(x, reinterpret_cast<const uint16_t *>(w2), oscale, scale, shift, n, h, wd, y, y_batch_stride,
+                            in_range, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
                                              int64_t n, int h, int wd, float *y, int64_t y_batch_stride,
                                              float *out_range_or_null, void *stream) {

@@ -30,6 +30,13 @@ hipError_t launch_stem(const float *x, const float *w, const float *scale, const
 hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale, const float *shift, int64_t n, int h,
                           int wd, float *y, int64_t y_bs, float *out_range, hipStream_t st);
 
+// k_stem_h2.hip: the stem on two fp16 terms (w2 = [2][11][2][32][16] fp16, per-output-channel scales in oscale[64];
+// in_range = range slots of the input images) and the pass that fills such slots with the largest |x|
+hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscale, const float *scale, const float *shift,
+                          int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
+                          hipStream_t st);
+hipError_t launch_range_absmax(const float *x, int64_t n, float *slots, hipStream_t st);
+
 // ---- k_conv1x1.hip ----------------------------------------------------------------------
 hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                           const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,

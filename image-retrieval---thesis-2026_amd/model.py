@@ -356,6 +356,22 @@ def _stem_weights_split3(w):
     return t.permute(1, 3, 0, 2, 4).contiguous()
 
 
+def _stem_weights_split2h(w):
+    """conv0 weights [64, 3, 7, 7] -> (w2, oscale): the two fp16 terms of W[oc] * ws[oc] (a power of two per output channel)
+    in the K order of mirx_stem_conv7_bn_relu_pool_split3 -- [2 oc blocks][11 steps][term][32 oc][16 k] -- and 1 / ws [64]."""
+    w = w.detach().float()
+    ws = _pow2_row_scales(w.reshape(64, -1))
+    wk = torch.zeros((64, 22, 8), dtype=torch.float32, device=w.device)
+    rows = (w * ws.view(-1, 1, 1, 1)).reshape(64, 21, 7)                   # [oc, (c, ky), kx]
+    wk[:, :21, 0:4] = rows[:, :, 0::2]
+    wk[:, :21, 4:7] = rows[:, :, 1::2]
+    wk = wk.reshape(64, 11, 16)
+    h = wk.to(torch.float16)
+    lo = (wk - h.float()).to(torch.float16)
+    t = torch.stack([h, lo], 0).reshape(2, 2, 32, 11, 16)                  # [term, block, oc, step, k]
+    return t.permute(1, 3, 0, 2, 4).contiguous(), (1.0 / ws).contiguous()
+
+
 def _split3_weights(w):
     """[cout, cin] fp32 -> the three bf16 terms of every weight (w = h + m + l exactly, 3 x 8 mantissa
     bits), laid out for mirx_conv1x1_bn_relu_split3: [cout // 128][cin // 16][3][128][16] bf16."""
@@ -786,14 +802,13 @@ class DenseNet121(nn.Module):
                 wt = m.conv.weight.detach().float()
                 w2, osc = _split2h_weights(wt.view(wt.shape[0], wt.shape[1]))
                 h2[name] = {"sc": sc, "sh": sh, "w2": w2, "osc": osc, "ks": float(sc.abs().max()), "kb": float(sh.abs().max())}
-        if "conv0_w3" not in cache:
-            cache["conv0_w3"] = _stem_weights_split3(f.conv0.weight)
+        cache["conv0_w2"] = _stem_weights_split2h(f.conv0.weight)
         cache["h2"] = h2
         return h2
 
     def _features_h2(self, x, cache):
         """-> feature map before norm5 [B, 1024, 7, 7]; every convolution on the matrix pipe with two fp16 terms per
-        operand (stem: three bf16 terms, 7 x 7 maps' 3x3 convs: fp32 Winograd), ranges carried in range slots."""
+        operand (7 x 7 maps' 3x3 convs: fp32 Winograd), ranges carried in range slots."""
         f = self.densenet121[0]
         lib = _lib.load()
         h2 = cache.get("h2") or self._prepare_h2(cache)
@@ -804,13 +819,16 @@ class DenseNet121(nn.Module):
         blocks = [(n, m) for n, m in f.named_children() if n.startswith("denseblock")]
         trans = [n for n, _ in f.named_children() if n.startswith("transition")]
         nlayers = sum(len(m) for _, m in blocks)
-        ranges = torch.zeros((len(blocks) + nlayers, 64), dtype=torch.float32, device=dev)      # one fill per forward
+        ranges = torch.zeros((len(blocks) + nlayers + 1, 64), dtype=torch.float32, device=dev)  # one fill per forward
         side = 56
         buf = torch.empty((b, blocks[0][1].cout, side, side), dtype=torch.float32, device=dev)
         sc, sh = cache["norm0"]
-        _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3_into(_ptr(x), _ptr(cache["conv0_w3"]), _ptr(sc), _ptr(sh), b, 224,
-                                                                224, _ptr(buf), blocks[0][1].cout * side * side,
-                                                                _ptr(ranges[0]), st), "mirx_stem_split3_into")
+        xr = ranges[len(blocks) + nlayers]                           # the range of the input images: one pass over them
+        _lib.check(lib.mirx_range_absmax(_ptr(x), x.numel(), _ptr(xr), st), "mirx_range_absmax")
+        w2, osc = cache["conv0_w2"]
+        _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split2h_into(_ptr(x), _ptr(w2), _ptr(osc), _ptr(sc), _ptr(sh), b, 224, 224,
+                                                                 _ptr(buf), blocks[0][1].cout * side * side, _ptr(xr),
+                                                                 _ptr(ranges[0]), st), "mirx_stem_split2h_into")
         row = len(blocks)
         for k, (name, blk) in enumerate(blocks):
             _dense_block_h2(blk, buf, h2[name], ranges[k], ranges[row:row + len(blk)], self.conv1x1_timer)

@@ -222,6 +222,14 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
  *       (mirx.model._conv3x3_weights_split2h), oscale = device fp32 [32] = 1 / that scale.  side 56 / 28 / 14.
  * (reference: the conv0 / conv2 calls inside torchvision densenet121, model.py:53-60)
  */
+/* mirx_range_absmax: folds the largest |x[i]| of a flat fp32 array into 64 range slots (zeroed by the caller) -- the range of
+ * the input images for mirx_stem_conv7_bn_relu_pool_split2h_into, the stem on two fp16 terms per operand (w2 = device fp16
+ * [2][11][2][32][16], oscale = device fp32 [64]: mirx.model._stem_weights_split2h; otherwise the contract of
+ * mirx_stem_conv7_bn_relu_pool_split3_into). */
+int mirx_range_absmax(const float *x, int64_t n, float *range_slots, void *stream);
+int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, const float *oscale, const float *scale,
+                                              const float *shift, int64_t n, int h, int w, float *y, int64_t y_batch_stride,
+                                              const float *in_range, float *out_range_or_null, void *stream);
 int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
                                              int64_t n, int h, int w, float *y, int64_t y_batch_stride,
                                              float *out_range_or_null, void *stream);
