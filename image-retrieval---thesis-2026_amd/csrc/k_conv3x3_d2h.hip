@@ -18,7 +18,8 @@
 //   * X: 16-channel stages; the padded strip ((R + 2) x (W + 2) pixels) is split into its two fp16 terms while it
 //     is staged and stored pixel-major -- [term][padded pixel][16 channels] fp16, the two 16-byte halves of a pixel
 //     at slot h ^ ((pixel >> 3) & 1) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
-//     ds_read_b128 per term.  Double-buffered, register-prefetched.
+//     ds_read_b128 per term.  Double-buffered; register-prefetched TWO stages ahead (two register sets), the split +
+//     LDS store of the next stage runs between the taps of the current one.
 //   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][2 terms][32 oc][16 c] fp16).  The 18 KiB of a
 //     stage go global -> LDS by DMA ONCE per workgroup (18 one-KiB pieces = one (tap, term) plane each, double-buffered,
 //     issued right after the stage barrier) and every wave reads its A fragments from there.  k_conv3x3_d3 lets every
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
     // ---- staging: item = (padded pixel, 8-channel half); thread t takes items t, t + 256, ... ----------------------
     constexpr int NITEM = 2 * NPIX;
     constexpr int IPT = (NITEM + 255) / 256;                  // items per thread (3 for 56 / 28, 2 for 14)
-    float rin[IPT][8];
+    float rin_a[IPT][8], rin_b[IPT][8];     // two sets: stage st + 2 loads while st + 1 waits for its split + store
     int g_off[IPT], l_off[IPT];
     bool inside[IPT];
 #pragma unroll
@@ -96,28 +97,30 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
         g_off[i] = (8 * hh * W + cy) * W + cx;                // + (stage * 16 + j) * W * W
         l_off[i] = live ? pix * 32 + ((hh ^ ((pix >> 3) & 1)) << 4) : -1;
     }
-    auto load = [&](int st) {
+    auto load = [&](int st, float (&rin)[IPT][8]) {
 #pragma unroll
         for (int i = 0; i < IPT; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) rin[i][j] = xi[(int64_t)(st * KC + j) * (W * W) + g_off[i]];
     };
-    auto store = [&](int buf) {
+    // split + store of ONE staging item (8 channels of one padded pixel): called between the taps of the stage before
+    auto store_item = [&](int buf, const float (&rin)[IPT][8], int i) {
         char *sb = sm + buf * STAGE;
+        u32x4 ph, pl;
 #pragma unroll
-        for (int i = 0; i < IPT; ++i) {
-            u32x4 ph, pl;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                unsigned th, tl;
-                split2h(inside[i] ? rin[i][2 * p] * x_scale : 0.f, inside[i] ? rin[i][2 * p + 1] * x_scale : 0.f, th, tl);
-                ph[p] = th; pl[p] = tl;
-            }
-            if (l_off[i] >= 0) {
-                *reinterpret_cast<u32x4 *>(sb + l_off[i]) = ph;
-                *reinterpret_cast<u32x4 *>(sb + l_off[i] + PLANE) = pl;
-            }
+        for (int p = 0; p < 4; ++p) {
+            unsigned th, tl;
+            split2h(inside[i] ? rin[i][2 * p] * x_scale : 0.f, inside[i] ? rin[i][2 * p + 1] * x_scale : 0.f, th, tl);
+            ph[p] = th; pl[p] = tl;
         }
+        if (l_off[i] >= 0) {
+            *reinterpret_cast<u32x4 *>(sb + l_off[i]) = ph;
+            *reinterpret_cast<u32x4 *>(sb + l_off[i] + PLANE) = pl;
+        }
+    };
+    auto store = [&](int buf, const float (&rin)[IPT][8]) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) store_item(buf, rin, i);
     };
 
     // ---- this wave's column blocks and this lane's pixels --------------------------------------------------------
@@ -175,19 +178,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
         acc[T] = c_;                                                                               \
     }
     const bool two = live_blk[1];                          // wave-uniform: waves 0..2 own two column blocks
-    dma_w(0, 0);
-    load(0);
-    store(0);
-    for (int st = 0; st < NST; ++st) {
+    // One stage.  LDS buffer `cur` holds stage st; `rstore` holds stage st + 1 (loaded one stage ago, complete since the
+    // vmcnt(0) below) and is split + stored into buffer cur ^ 1 BETWEEN the taps, in the shadow of the MFMAs -- when the
+    // split ran after the tap loop the matrix pipe idled for it (42 % busy); `rnext` receives stage st + 2.
+    auto stage = [&](int st, float (&rnext)[IPT][8], const float (&rstore)[IPT][8]) {
         const int cur = st & 1;
         // stage st visible: activations stored by every wave, and THIS wave's weight DMA landed (vmcnt(0): the compiler's
         // own wait before s_barrier does not cover the asynchronous LDS writes; no counted wait -- LDS-DMA and loads to
         // registers do not retire in one common order, see k_conv1x1_h2); buffers cur ^ 1 free
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        dma_w(st + 1 < NST ? st + 1 : st, cur ^ 1);        // branch-free: the last stage re-loads itself
+        dma_w(st + 1 < NST ? st + 1 : st, cur ^ 1);        // branch-free: the last stages re-load the last one
 #ifndef MIRX_D2H_EXP_NOLOAD          // diagnostic build: no activation prefetch (results wrong) -> time without HBM latency
-        load(st + 1 < NST ? st + 1 : st);
+        load(st + 2 < NST ? st + 2 : NST - 1, rnext);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         const char *sb = sm + cur * STAGE;
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
                 __builtin_amdgcn_sched_barrier(0);
                 if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
                 if (tap + 1 < 9) MIRX_D2H_READB(b0, tap + 1, 0)
+                if (tap % 3 == 1 && tap / 3 < IPT) store_item(cur ^ 1, rstore, tap / 3);      // taps 1, 4, 7
                 __builtin_amdgcn_sched_barrier(0);
                 if (tap & 1) { MIRX_D2H_MFMA(1, a1, b1) } else { MIRX_D2H_MFMA(1, a0, b1) }
             }
@@ -216,13 +220,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict_
                     MIRX_D2H_READB(b1, tap + 1, 0)
                     if (tap & 1) { MIRX_D2H_READA(a0, tap + 1) } else { MIRX_D2H_READA(a1, tap + 1) }
                 }
+                if (tap % 3 == 1 && tap / 3 < IPT) store_item(cur ^ 1, rstore, tap / 3);
                 __builtin_amdgcn_sched_barrier(0);
                 if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) b0[q] = b1[q];
             }
         }
-        store(cur ^ 1);
+    };
+    dma_w(0, 0);
+    load(0, rin_a);
+    load(1, rin_b);
+    store(0, rin_a);
+    static_assert(NST % 2 == 0, "the stage loop runs in pairs");
+    for (int st = 0; st < NST; st += 2) {
+        stage(st, rin_a, rin_b);                           // fetch st + 2 into a, publish b = st + 1
+        stage(st + 1, rin_b, rin_a);
     }
 #undef MIRX_D2H_READA
 #undef MIRX_D2H_READB
