@@ -58,7 +58,8 @@ def test_linear_split3_argument_checks():
     y = torch.zeros(4, 128, device=dev)
     w = torch.zeros(128 * 24 * 3, dtype=torch.bfloat16, device=dev)
     assert lib.mirx_linear_split3(_vp(x), 4, 24, _vp(w), None, 128, 0, None, None, _vp(y), None) != 0   # k % 16
-    assert lib.mirx_linear_split3(_vp(x), 4, 16, _vp(w), None, 128, 2, None, None, _vp(y), None) != 0   # act
+    assert lib.mirx_linear_split3(_vp(x), 4, 16, _vp(w), None, 128, 3, None, None, _vp(y), None) != 0   # act
+    assert lib.mirx_linear_split3(_vp(x), 4, 16, _vp(w), None, 128, 2, _vp(y), None, _vp(y), None) != 0   # tanh-GELU has no residual form
     assert lib.mirx_linear_split3(_vp(x), 0, 16, _vp(w), None, 128, 0, None, None, _vp(y), None) == 0   # empty batch
 
 
@@ -213,3 +214,17 @@ def test_linear_out_bound_holds():
         assert float(y.abs().max()) <= mm._linear_out_bound(ln, lin) * (1 + 1e-6)
         assert float(y[:, 32:64].abs().max()) <= mm._linear_out_bound(ln, lin, slice(32, 64)) * (1 + 1e-6)
         assert mm._linear_out_bound(ln, lin, slice(32, 64)) <= mm._linear_out_bound(ln, lin) + 1e-9
+
+
+@pytest.mark.parametrize("kind", ["split3", "split2h"])
+def test_linear_tanh_gelu_epilogue(kind):
+    """act = 2: the tanh-form GELU of the SigLIP MLP (transformers `gelu_pytorch_tanh`) fused in the Linear epilogue."""
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(144, 208).to(dev)
+    x = torch.randn(3, 37, 144, device=dev).clamp_(-4, 4)
+    with torch.no_grad():
+        got = mm._linear_s3(lin, x, act=2) if kind == "split3" else mm._linear_h2(lin, x, 4.0, act=2)
+        want = torch.nn.functional.gelu(lin.double()(x.double()), approximate="tanh")
+    assert float((got.double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
