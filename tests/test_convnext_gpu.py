@@ -49,3 +49,27 @@ def test_embeddings_match_cpu_restatement():
     assert y.shape == (2, 256)
     assert float((y.norm(dim=1) - 1).abs().max()) < 1e-6
     assert float((y[:1] - ref).abs().max()) <= 1e-5, float((y[:1] - ref).abs().max())
+
+
+def test_rows_do_not_depend_on_the_batch():
+    """the bench's batch (64 at 384 x 384) against the same images embedded two at a time (<= 1e-6), and a
+    row of it against the CPU restatement (1e-5)."""
+    from mirx.model import ConvNeXtV2
+    torch.manual_seed(0)
+    m = ConvNeXtV2(embedding_dim=256).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if ".grn." in n:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(64, 3, 384, 384, generator=torch.Generator().manual_seed(4))
+    m = m.cuda()
+    with torch.no_grad():
+        big = m(x.cuda()).cpu()
+        small = torch.cat([m(x[i:i + 2].cuda()).cpu() for i in (0, 30, 62)])
+        ref = OC.embed(x[63:64], sd)
+    assert float((big[[0, 1, 30, 31, 62, 63]] - small).abs().max()) <= 1e-6
+    assert float((big[63:64] - ref).abs().max()) <= 1e-5

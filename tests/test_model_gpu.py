@@ -462,3 +462,20 @@ def test_split2h_path_matches_oracle_and_legacy(model_and_sd):
     with torch.no_grad():
         solo = m(x[2:3].cuda()).cpu()                   # alone, the small image gets a much finer scale
     assert float((solo - e2[2:3]).abs().max()) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
+    """the bench embeds 2048 images per stream -- other grid sizes, 64-bit strides, and (two-fp16 path) a
+    range that is the maximum over the WHOLE batch.  The same 6 images embedded alone and as rows of a 2048-image batch
+    must agree to 1e-6, and both with the CPU restatement to 1e-5."""
+    m, sd = model_and_sd
+    g = torch.Generator(device="cuda").manual_seed(11)
+    big = torch.randn(2048, 3, 224, 224, generator=g, device="cuda")
+    rows = [0, 1, 777, 1024, 2046, 2047]
+    with torch.no_grad():
+        e_big = m(big)[rows].cpu()
+        e_small = m(big[rows].contiguous()).cpu()
+        ref = OD.embed(big[rows].cpu(), sd)
+    assert float((e_big - e_small).abs().max()) <= 1e-6
+    assert float((e_big - ref).abs().max()) <= 1e-5

@@ -74,3 +74,27 @@ def test_medsiglip_head_dim_72_uses_fused_tower_path():
     assert calls == [72, 72]                                       # one launch per encoder layer, head_dim 72
     assert float((y - ref).abs().max()) <= 1e-5
     assert m.verify_attention_output("cuda")                       # attention maps still come from the module path
+
+
+def test_dinov2_rows_do_not_depend_on_the_batch():
+    """the bench's batch (32 at 518 x 518, 1370 tokens) against the same images embedded two at a time
+    (<= 1e-6) and against the CPU restatement (1e-5)."""
+    from mirx.model import DinoV2
+    torch.manual_seed(0)
+    m = DinoV2(embedding_dim=256).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("gamma"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(32, 3, 518, 518, generator=torch.Generator().manual_seed(5))
+    m = m.cuda()
+    with torch.no_grad():
+        big = m(x.cuda()).cpu()
+        small = torch.cat([m(x[i:i + 2].cuda()).cpu() for i in (0, 14, 30)])
+        ref = OV.embed(x[31:32], sd)
+    assert float((big[[0, 1, 14, 15, 30, 31]] - small).abs().max()) <= 1e-6
+    assert float((big[31:32] - ref).abs().max()) <= 1e-5
