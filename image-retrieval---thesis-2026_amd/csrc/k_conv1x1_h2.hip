@@ -37,7 +37,7 @@ constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage 
 constexpr int PLANE_B = CP * KC * 2;
 constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // 16 KiB
 
-template <bool PROLOGUE, bool RELU_OUT>
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS>
 __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
                                                        const float *__restrict__ bias, int64_t n, int hw, int cout,
                                                        float *__restrict__ y, int64_t ybs,
                                                        const float *__restrict__ in_amax, float in_ks, float in_kb,
-                                                       unsigned *__restrict__ out_amax) {
+                                                       unsigned *__restrict__ out_amax, float y_ks, float y_kb,
+                                                       float *__restrict__ y_inv_out) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ float sBias[CM], sOsc[CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -58,7 +59,16 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
 
     // ---- the input range -> x_scale (a power of two), identical in every lane --------------------------------
     float x_scale, x_inv;
-    range_scales(fmaf(in_ks, in_amax ? range_read(in_amax) : 0.f, in_kb), x_scale, x_inv);
+    const float x_bound = fmaf(in_ks, in_amax ? range_read(in_amax) : 0.f, in_kb);
+    range_scales(x_bound, x_scale, x_inv);
+    // YTERMS: the output is written already split into its two fp16 terms, scaled by 2^t with
+    //     |y| <= y_ks * x_bound + y_kb      (y_ks = max_o sum_c |W[o, c]|, y_kb = max |bias|: a provable bound known BEFORE the
+    // kernel runs, unlike the true maximum) * 2^t in [2^14, 2^15); 2^-t goes to y_inv_out[0] for the consumer.
+    float y_scale = 1.f, y_inv = 1.f;
+    if (YTERMS) {
+        range_scales(fmaf(y_ks, x_bound, y_kb), y_scale, y_inv);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) y_inv_out[0] = y_inv;
+    }
 
     // ---- staging assignments ------------------------------------------------------------------------
     // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
@@ -196,6 +206,47 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 64 wn + 32 ni + (lane & 31)
     float vmax = 0.f;
+    if (YTERMS) {
+        // y as the 3x3 conv wants it: [image][group g of 16 channels][term][pixel][16] fp16, where group g = 4 wm + 2 mi +
+        // (lane >> 5) holds exactly the 16 channels this lane owns in accumulator tile mi (the consumer's weights are
+        // permuted to the same channel order: mirx.model.YTERMS_CHANNEL_ORDER): a lane writes 32 contiguous bytes per term,
+        // a half-wave 1 KiB
+        uint16_t *yt = reinterpret_cast<uint16_t *>(y);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
+            if (pp >= total) continue;
+            const int64_t bimg = pp / hw, off = pp % hw;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int g = 4 * wm + 2 * mi + (lane >> 5);
+                u32x4 h0, h1, l0, l1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x2 v;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * j + e;
+                        const int ch = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float t = fmaf(acc[mi][ni][r], sOsc[ch], sBias[ch]);
+                        t = t < 0.f ? 0.f : t;
+                        v[e] = t * y_scale;
+                    }
+                    const f16x2 hh = __builtin_convertvector(v, f16x2);
+                    const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                    const f16x2 ll = __builtin_convertvector(r1, f16x2);
+                    if (j < 4) { h0[j] = __builtin_bit_cast(unsigned, hh); l0[j] = __builtin_bit_cast(unsigned, ll); }
+                    else { h1[j - 4] = __builtin_bit_cast(unsigned, hh); l1[j - 4] = __builtin_bit_cast(unsigned, ll); }
+                }
+                uint16_t *dst = yt + (((bimg * 8 + g) * 2) * (int64_t)hw + off) * 16;
+                *reinterpret_cast<u32x4 *>(dst) = h0;
+                *reinterpret_cast<u32x4 *>(dst + 8) = h1;
+                *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = l0;
+                *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16 + 8) = l1;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
@@ -221,24 +272,28 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, hipStream_t st) {
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM || !oscale) return hipErrorInvalidValue;
+    const bool yterms = y_inv_out != nullptr;
+    if (yterms && (cout != CM || !relu_out || !scale)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)STAGE;
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
-#define MIRX_H2C(P, R)                                                                                     \
+#define MIRX_H2C(P, R, T)                                                                                  \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R>),             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T>),          \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
-                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa);                                \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out);         \
     }
-    if (scale) {
-        if (relu_out) MIRX_H2C(true, true) else MIRX_H2C(true, false)
+    if (yterms) {
+        MIRX_H2C(true, true, true)
+    } else if (scale) {
+        if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)
     } else {
-        if (relu_out) MIRX_H2C(false, true) else MIRX_H2C(false, false)
+        if (relu_out) MIRX_H2C(false, true, false) else MIRX_H2C(false, false, false)
     }
 #undef MIRX_H2C
     return hipGetLastError();

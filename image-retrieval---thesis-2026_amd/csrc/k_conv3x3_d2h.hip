@@ -274,6 +274,200 @@ hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, i
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_d2p: the same convolution reading the bottleneck ALREADY SPLIT into its two fp16 terms by the 1x1 conv that
+// produced it (k_conv1x1_h2<.., YTERMS>): yt = [image][group of 16 channels][term][pixel][16] fp16, scaled by 2^t, 2^-t in
+// in_inv[0].  Staging is then pure LDS DMA -- no register prefetch, no split, no LDS stores: piece j of a term plane =
+// padded pixels 32 j .. 32 j + 31 (lane l -> pixel 32 j + l / 2, 16-byte slot l & 1, which must hold channel chunk
+// (l & 1) ^ ((pixel >> 3) & 1)); a lane's source offset is its pixel's position inside the image, or an offset beyond the
+// buffer's num_records for the padding ring (out-of-range buffer loads return zero: the halo needs no branch and no
+// pre-zeroed LDS).  Weights by DMA as in k_conv3x3_d2h.  The tap loop is k_conv3x3_d2h's.
+template <int W, int R>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
+                                                        const float *__restrict__ oscale, float *__restrict__ out,
+                                                        int64_t out_bs, const float *__restrict__ in_inv,
+                                                        unsigned *__restrict__ out_range) {
+    constexpr int PW = W + 2, PR = R + 2;     // padded strip
+    constexpr int NPIX = PR * PW;             // padded pixels of a stage
+    constexpr int NP = (NPIX + 31) / 32;      // 1-KiB DMA pieces per term plane
+    constexpr int PLANE = NP * 32 * 32;       // bytes of one term of one stage (32 B per pixel, rounded up to whole pieces)
+    constexpr int STAGE = 2 * PLANE;
+    constexpr int WSTAGE = 9 * 2 * COUT * KC * 2;   // bytes of one stage of weights (18 KiB): 18 pieces of 1 KiB
+    constexpr int W_LDS0 = 2 * STAGE;               // weight buffers behind the two activation buffers
+    constexpr int NOUT = R * W;               // output pixels of a full strip
+    constexpr int NBLK = (NOUT + 31) / 32;    // 7
+    static_assert(NBLK <= 8, "two column blocks per wave");
+    constexpr int PPW = (2 * NP + 3) / 4;     // activation pieces per wave and stage (both terms)
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half = lane >> 5, n = lane & 31;
+    const int strip = blockIdx.x;
+    const int64_t img = blockIdx.y;
+    const int oy0 = strip * R;                                // first output row of the strip
+    constexpr unsigned IMG_BYTES = 16u * W * W * 32u;        // 8 groups x 2 terms x W*W pixels x 32 B
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(yt + img * (int64_t)(IMG_BYTES / 2)), 0,
+                                                                           IMG_BYTES, 0x00020000);
+    // this wave's activation pieces: q = wave + 4 i over the 2 NP pieces of a stage (term = q / NP, piece = q % NP); the
+    // source offset of this lane inside a term plane, or "out of range" for the zero ring
+    unsigned a_src[PPW];
+    int a_dst[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave + 4 * i;
+        const int term = q / NP, piece = q % NP;
+        const int pix = piece * 32 + (lane >> 1);
+        const int pr = pix / PW, pc = pix % PW;
+        const int iy = oy0 - 1 + pr, ix = pc - 1;
+        const bool inside = q < 2 * NP && pix < NPIX && iy >= 0 && iy < W && ix >= 0 && ix < W;
+        const int chunk = (lane & 1) ^ ((pix >> 3) & 1);
+        a_src[i] = inside ? (unsigned)((term * W * W + iy * W + ix) * 32 + chunk * 16) : 0xfffffff0u;
+        a_dst[i] = q < 2 * NP ? term * PLANE + piece * 1024 : -1;
+    }
+    auto dma_a = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (a_dst[i] >= 0) {                               // wave-uniform
+                const unsigned v = a_src[i] == 0xfffffff0u ? a_src[i] : a_src[i] + (unsigned)st * (2u * W * W * 32u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, LDS_PTR(sm + buf * STAGE + a_dst[i]), 16, v, 0, 0, 0);
+            }
+    };
+
+    // ---- this wave's column blocks and this lane's pixels --------------------------------------------------------
+    int pbase[2];                                             // padded index of the pixel's tap (0, 0) corner
+    bool live_blk[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int blk = wave + 4 * t;
+        live_blk[t] = blk < NBLK;                              // wave-uniform
+        int p = blk * 32 + n;
+        if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
+        pbase[t] = (p / W) * PW + (p % W);
+    }
+    const int a_off = n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w3, 0, NST * WSTAGE, 0x00020000);
+    const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    auto dma_w = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int piece = wave + 4 * i;               // 18 pieces: waves 0, 1 take five, waves 2, 3 four
+            if (piece < 18)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + W_LDS0 + buf * WSTAGE + piece * 1024), 16, w_voff,
+                                                         st * WSTAGE + piece * 1024, 0, 0);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+#define MIRX_D2P_READA(DST, TAP)                                                                   \
+    {                                                                                              \
+        DST[0] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP)) * 1024 + a_off);                \
+        DST[1] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP) + 1) * 1024 + a_off);            \
+    }
+#define MIRX_D2P_READB(DST, TAP, T)                                                                \
+    {                                                                                              \
+        const int pix_ = pbase[T] + ((TAP) / 3) * PW + (TAP) % 3;                                  \
+        const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 3) & 1)) << 4);                      \
+        DST[0] = *reinterpret_cast<const f16x8 *>(pb_);                                            \
+        DST[1] = *reinterpret_cast<const f16x8 *>(pb_ + PLANE);                                    \
+    }
+#define MIRX_D2P_MFMA(T, A, B)                                                                     \
+    {                                                                                              \
+        f32x16 c_ = acc[T];                                                                        \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], c_, 0, 0, 0);                      \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], c_, 0, 0, 0);                      \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], c_, 0, 0, 0);                      \
+        acc[T] = c_;                                                                               \
+    }
+    const bool two = live_blk[1];                          // wave-uniform: waves 0..2 own two column blocks
+    dma_w(0, 0);
+    dma_a(0, 0);
+    for (int st = 0; st < NST; ++st) {
+        const int cur = st & 1;
+        // stage st landed (this wave's DMA: vmcnt(0); every wave's: the barrier); buffers cur ^ 1 free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < NST) {                                // wave-uniform
+            dma_w(st + 1, cur ^ 1);
+            dma_a(st + 1, cur ^ 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = sm + cur * STAGE;
+        const char *wb = sm + W_LDS0 + cur * WSTAGE;
+        f16x8 a0[2], a1[2], b0[2], b1[2];
+        MIRX_D2P_READA(a0, 0)
+        MIRX_D2P_READB(b0, 0, 0)
+        if (two) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                MIRX_D2P_READB(b1, tap, 1)
+                if (tap + 1 < 9) {
+                    if (tap & 1) { MIRX_D2P_READA(a0, tap + 1) } else { MIRX_D2P_READA(a1, tap + 1) }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap & 1) { MIRX_D2P_MFMA(0, a1, b0) } else { MIRX_D2P_MFMA(0, a0, b0) }
+                if (tap + 1 < 9) MIRX_D2P_READB(b0, tap + 1, 0)
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap & 1) { MIRX_D2P_MFMA(1, a1, b1) } else { MIRX_D2P_MFMA(1, a0, b1) }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) {
+                    MIRX_D2P_READB(b1, tap + 1, 0)
+                    if (tap & 1) { MIRX_D2P_READA(a0, tap + 1) } else { MIRX_D2P_READA(a1, tap + 1) }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap & 1) { MIRX_D2P_MFMA(0, a1, b0) } else { MIRX_D2P_MFMA(0, a0, b0) }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) b0[q] = b1[q];
+            }
+        }
+    }
+#undef MIRX_D2P_READA
+#undef MIRX_D2P_READB
+#undef MIRX_D2P_MFMA
+
+    // ---- outputs straight from the accumulators: register r = channel 8 (r >> 2) + (r & 3) + 4 half, lane = pixel ----
+    const float x_inv = in_inv[0];
+    float *oi = out + img * out_bs + (int64_t)oy0 * W;
+    float osc[16], vmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = (wave + 4 * t) * 32 + n;
+        if (live_blk[t] && p < NOUT && oy0 + p / W < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
+                const float v = acc[t][r] * osc[r];
+                vmax = range_max(vmax, v);
+                oi[(int64_t)oc * (W * W) + p] = v;
+            }
+        }
+    }
+    if (out_range) range_publish(out_range, vmax, lane);
+}
+
+template <int W, int R>
+hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
+                      const float *in_inv, float *out_range, hipStream_t st) {
+    constexpr int NP = ((R + 2) * (W + 2) + 31) / 32;
+    const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_conv3x3_d2p<W, R>), dim3((W + R - 1) / R, (unsigned)n), dim3(256), lds, st, yt, w2, oscale, out,
+                       out_bs, in_inv, reinterpret_cast<unsigned *>(out_range));
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
@@ -283,6 +477,16 @@ hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *o
     if (side == 56) return launch_d2h<56, 4>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
     if (side == 28) return launch_d2h<28, 8>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
     if (side == 14) return launch_d2h<14, 14>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535 || !in_inv || !oscale) return hipErrorInvalidValue;
+    if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
+    if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
+    if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
     return hipErrorInvalidValue;
 }
 

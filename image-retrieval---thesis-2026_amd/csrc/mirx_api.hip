@@ -731,8 +731,34 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                "conv1x1_split2h: in_ks / in_kb are non-negative; without range slots in_kb is the bound itself");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
                                reinterpret_cast<const uint16_t *>(w2), oscale, bias_or_null, n, hw, cout, relu_out, y,
-                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null,
+                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr,
                                reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
+                                       const float *shift1, const void *w2, const float *oscale, const float *bias,
+                                       int64_t n, int hw, void *y_terms, const float *in_range, float in_ks, float in_kb,
+                                       float y_ks, float y_kb, float *y_inv_out, void *stream) {
+    MIRX_CHECK(n >= 0 && hw >= 1 && cin >= 16 && cin % 16 == 0, "conv1x1_split2h_terms: cin must be a multiple of 16");
+    MIRX_CHECK(n == 0 || (x && w2 && y_terms && oscale && scale1 && shift1 && bias && in_range && y_inv_out),
+               "conv1x1_split2h_terms: null buffer");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1_split2h_terms: batch stride smaller than the channel prefix");
+    MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && y_ks >= 0.f && y_kb >= 0.f, "conv1x1_split2h_terms: bounds are non-negative");
+    MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1, shift1, reinterpret_cast<const uint16_t *>(w2), oscale, bias, n,
+                               hw, 128, 1, reinterpret_cast<float *>(y_terms), 0, in_range, in_ks, in_kb, nullptr, y_ks, y_kb,
+                               y_inv_out, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms: side must be 56, 28 or 14");
+    MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
+    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_terms: output batch stride too small");
+    MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                side, out, out_batch_stride, y_inv, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

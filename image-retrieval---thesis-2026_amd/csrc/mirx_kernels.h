@@ -78,7 +78,7 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, hipStream_t st);
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, hipStream_t st);
 
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
@@ -113,6 +113,10 @@ hipError_t launch_patchify(const float *x, int64_t n, int c, int h, int w, int p
 hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, const float *v, int64_t kv_rs,
                                   const uint8_t *key_mask, int64_t batch, int heads, int head_dim, int nq, int nk,
                                   float scale, float *out, hipStream_t st);
+
+// k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
+hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

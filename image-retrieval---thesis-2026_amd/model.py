@@ -206,23 +206,36 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
 
 def _dense_block_h2(block, buf, cache, brange, lranges, timer=None):
     """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, h, h] already holds the first block.cin
-    channels and `brange` (64 range slots) bounds them; every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2
-    epilogue; reads brange, publishes the bottleneck's range in its row of `lranges`) -> conv3x3 (reads that row,
-    writes 32 channels into the buffer, folds their range into brange)."""
+    channels and `brange` (64 range slots) bounds them.  Every layer on the 56 / 28 / 14 maps: conv1x1 (norm1 + relu1
+    prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT into fp16 terms, scaled by a bound it derives
+    from brange before it runs (2^-t goes to the layer's row of `lranges`); conv3x3 stages those terms by DMA, writes 32
+    channels into the buffer and folds their range into brange.  7 x 7 maps: fp32 bottleneck + fp32 Winograd."""
     lib = _lib.load()
     b, _, h, w = buf.shape
     st = _stream(buf.device)
     c = block.cin
-    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)
+    terms = CONV3X3_KERNEL_H2.get(h, "wino") == "terms"
+    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)      # fp32 map, or the same bytes as terms
     for li, name in enumerate(block.keys()):
         e = cache[name]
+        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
         ev = _timer_start(timer)
+        if terms:
+            _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
+                                                              _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, _ptr(y),
+                                                              _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
+                                                              _ptr(lranges[li]), st), "mirx_conv1x1_bn_relu_split2h_terms")
+            _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
+            _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
+                                                          block.cout * h * w, _ptr(lranges[li]), _ptr(brange), st),
+                       "mirx_conv3x3_direct_terms_nchw")
+            c += GROWTH
+            continue
         _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
                                                     _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, y.shape[1], 1,
                                                     _ptr(y), y.shape[1] * h * w, _ptr(brange), e["ks"], e["kb"],
                                                     _ptr(lranges[li]), st), "mirx_conv1x1_bn_relu_split2h")
         _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
-        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
         if CONV3X3_KERNEL_H2.get(h, "wino") == "direct2h":
             _lib.check(lib.mirx_conv3x3_direct_split2h_nchw(_ptr(y), _ptr(e["c3w2"]), _ptr(e["c3osc"]), b, h, dst,
                                                             block.cout * h * w, _ptr(lranges[li]), _ptr(brange), st),
@@ -325,11 +338,19 @@ def _conv3x3_weights_split3(w):
     return t.permute(2, 4, 0, 1, 3).contiguous()
 
 
-def _conv3x3_weights_split2h(w):
+# Channel order of the pre-split bottleneck (mirx_conv1x1_bn_relu_split2h_terms): slot j of group g holds channel
+# 64 (g >> 2) + 32 ((g >> 1) & 1) + 4 (g & 1) + (j & 3) + 8 (j >> 2) -- the 16 channels one lane of the 1x1-conv kernel owns.
+YTERMS_CHANNEL_ORDER = [64 * (g >> 2) + 32 * ((g >> 1) & 1) + 4 * (g & 1) + (j & 3) + 8 * (j >> 2)
+                        for g in range(8) for j in range(16)]
+
+
+def _conv3x3_weights_split2h(w, channel_order=None):
     """conv2 weights [32, 128, 3, 3] -> (w2, oscale): the two fp16 terms of W[oc] * ws[oc] (ws a power of two per output
     channel) laid out for mirx_conv3x3_direct_split2h_nchw: [stage = c // 16][tap = 3 ky + kx][term][oc][c % 16] fp16, and
-    oscale = 1 / ws fp32 [32]."""
+    oscale = 1 / ws fp32 [32].  channel_order: input channels re-ordered first (YTERMS_CHANNEL_ORDER for the terms path)."""
     w = w.detach().float()
+    if channel_order is not None:
+        w = w[:, torch.as_tensor(channel_order, device=w.device)]
     oc, cin = w.shape[0], w.shape[1]
     ws = _pow2_row_scales(w.reshape(oc, -1))
     wf = w * ws.view(-1, 1, 1, 1)
@@ -428,9 +449,9 @@ def _stream(dev):
 
 CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
 # Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations in "range slots" (include/mirx.h,
-# mirx_conv1x1_bn_relu_split2h); kernels per map side must publish ranges: "direct2h" or "wino" (fp32 Winograd).
+# mirx_conv1x1_bn_relu_split2h); kernels per map side must publish ranges: "terms", "direct2h" or "wino" (fp32 Winograd).
 SPLIT2H_DENSENET = True
-CONV3X3_KERNEL_H2 = {56: "direct2h", 28: "direct2h", 14: "direct2h", 7: "wino"}
+CONV3X3_KERNEL_H2 = {56: "terms", 28: "terms", 14: "terms", 7: "wino"}       # "terms": pre-split bottleneck (see _dense_block_h2)
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
@@ -794,8 +815,12 @@ class DenseNet121(nn.Module):
                     sc1, sh1, w1, b1 = cache[name][lname][0], cache[name][lname][1], cache[name][lname][2], cache[name][lname][3]
                     w2, osc = _split2h_weights(w1.view(w1.shape[0], w1.shape[1]))
                     c3w2, c3osc = _conv3x3_weights_split2h(layer.conv2.weight)
+                    c3w2p, _ = _conv3x3_weights_split2h(layer.conv2.weight, YTERMS_CHANNEL_ORDER)
                     blk[lname] = {"sc1": sc1, "sh1": sh1, "b1": b1, "w2": w2, "osc": osc, "c3w2": c3w2, "c3osc": c3osc,
-                                  "u": cache[name][lname][6][0], "ks": float(sc1.abs().max()), "kb": float(sh1.abs().max())}
+                                  "c3w2p": c3w2p, "u": cache[name][lname][6][0], "ks": float(sc1.abs().max()),
+                                  "kb": float(sh1.abs().max()),
+                                  # |relu(W x + b)| <= max_o sum_c |W[o, c]| * max|x| + max|b|: the bottleneck's bound
+                                  "yks": float(w1.view(w1.shape[0], -1).abs().sum(dim=1).max()), "ykb": float(b1.abs().max())}
                 h2[name] = blk
             elif name.startswith("transition"):
                 sc, sh = cache[name][0], cache[name][1]

@@ -210,6 +210,26 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                                  float *out_range_or_null, void *stream);
 
 /*
+ * The dense layer with the 128-channel bottleneck handed over ALREADY SPLIT into its two fp16 terms (same bytes as fp32,
+ * but the 3x3 conv then stages it by LDS DMA alone -- no register prefetch, no split, no LDS stores -- and the 1x1 conv
+ * writes 16-byte runs instead of 4-byte channel-plane stores):
+ *   mirx_conv1x1_bn_relu_split2h_terms: mirx_conv1x1_bn_relu_split2h for cout = 128 with relu, writing
+ *       y_terms = device fp16 [n][8 groups][2 terms][hw][16]: group g holds the 16 channels
+ *       64 (g >> 2) + 32 ((g >> 1) & 1) + 4 (g & 1) + {0..3, 8..11, 16..19, 24..27} (mirx.model.YTERMS_CHANNEL_ORDER; the
+ *       consumer's weights use the same order), values scaled by 2^t where |y| <= y_ks * (in_ks * range + in_kb) + y_kb
+ *       (y_ks = max_o sum_c |W[o, c]|, y_kb = max |bias|: a bound known before the kernel runs) is brought into
+ *       [2^14, 2^15); y_inv_out[0] receives 2^-t.
+ *   mirx_conv3x3_direct_terms_nchw: mirx_conv3x3_direct_split2h_nchw reading such y_terms and y_inv; the padding ring of the
+ *       staged strip comes from out-of-range buffer loads (zero), w2 in the permuted channel order.
+ */
+int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
+                                       const float *shift1, const void *w2, const float *oscale, const float *bias,
+                                       int64_t n, int hw, void *y_terms, const float *in_range, float in_ks, float in_kb,
+                                       float y_ks, float y_kb, float *y_inv_out, void *stream);
+int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null, void *stream);
+
+/*
  * Range-publishing forms of the DenseNet producers (the two-fp16-term kernels need the range of what they read; see
  * mirx_conv1x1_bn_relu_split2h).  `out_range_or_null` = device fp32 [64] range slots of the destination buffer; every
  * workgroup folds the largest |value| it wrote into slot (workgroup % 64) with an unsigned atomic max.

@@ -479,3 +479,50 @@ def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
         ref = OD.embed(big[rows].cpu(), sd)
     assert float((e_big - e_small).abs().max()) <= 1e-6
     assert float((e_big - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,batch,cin,mag", [(56, 2, 64, 1.0), (28, 3, 256, 25.0), (14, 5, 512, 1e-2), (14, 1, 1008, 1.0)])
+def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag):
+    """conv1x1 -> pre-split fp16-term bottleneck -> conv3x3 (mirx_conv1x1_bn_relu_split2h_terms +
+    mirx_conv3x3_direct_terms_nchw) against a float64 dense layer relu(bn2(conv1(relu(bn1(x))))) -> conv2: 3e-6 of the
+    largest output at any input magnitude; the halo ring of the DMA-staged strips is zero (out-of-range buffer loads);
+    neighbours of the written channel slice untouched; the output range published exactly."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side + cin)
+    ctot = cin + 64
+    hw = side * side
+    buf = torch.randn(batch, ctot, side, side, generator=g, device=dev) * mag
+    buf[:, cin:] = 7.0 * mag
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3 * mag
+    w1 = torch.randn(128, cin, generator=g, device=dev) / cin ** 0.5
+    b1 = torch.randn(128, generator=g, device=dev) * 0.2 * mag
+    w3 = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    assert sorted(YTERMS_CHANNEL_ORDER) == list(range(128))
+    w2, osc = _split2h_weights(w1)
+    c3, c3osc = _conv3x3_weights_split2h(w3, YTERMS_CHANNEL_ORDER)
+    y = torch.empty((batch, 128, side, side), device=dev)               # the same bytes, written as fp16 terms
+    brange = torch.zeros(64, device=dev)
+    brange[5] = float(buf[:, :cin].abs().max())
+    yinv = torch.zeros(64, device=dev)
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(buf), ctot * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), batch, hw,
+                                                      vp(y), vp(brange), float(sc.abs().max()), float(sh.abs().max()),
+                                                      float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv), None),
+               "terms")
+    rng_before = float(brange.max())
+    _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), batch, side, vp(buf, 4 * cin * hw), ctot * hw,
+                                                  vp(yinv), vp(brange), None), "conv3x3_terms")
+    torch.cuda.synchronize()
+    x64 = torch.relu(buf[:, :cin].double().cpu() * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None])
+    y64 = torch.relu(torch.einsum("oc,bchw->bohw", w1.double().cpu(), x64) + b1.double().cpu()[None, :, None, None])
+    want = torch.nn.functional.conv2d(y64, w3.double().cpu(), None, padding=1)
+    got = buf[:, cin:cin + 32].double().cpu()
+    assert float((got - want).abs().max()) < 3e-6 * float(want.abs().max())
+    assert bool((buf[:, cin + 32:] == 7.0 * mag).all())                  # neighbours untouched
+    assert float(yinv[0]) > 0 and float(brange.max()) == max(rng_before, float(buf[:, cin:cin + 32].abs().max()))

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--no-split3-linear", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (tail overlap)")
     ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
-    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (direct2h | wino)")
+    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (terms | direct2h | wino)")
     a = ap.parse_args()
     if a.no_split3_linear:
         import mirx.model as mm
