@@ -28,11 +28,12 @@ constexpr int ITH = 2 * (CTH - 1) + 7;       // 39 input rows
 constexpr int ITW = 2 * (CTW - 1) + 7;       // 35 input cols
 constexpr int PH = 24;                       // plane pitch: 18 columns used (+ 3 read ahead)
 constexpr int PLANE = 3 * ITH * PH;          // floats per parity plane
-constexpr int OCB = 32;                      // output channels per workgroup
+constexpr int OCB = 32;                      // output channels per MFMA row block
+constexpr int NOB = 2;                       // row blocks per workgroup: all 64 channels (a split B fragment feeds both)
 constexpr int NSTEP = 11;                    // MFMA steps: 22 (c, ky) rows, row 21 = zero weights
 constexpr int CONV_PITCH = 260;              // 255 pixels + pad, 260 = 4 (mod 32) banks per channel
 constexpr int S_IN = 2 * PLANE;
-constexpr int S_CONV = OCB * CONV_PITCH;
+constexpr int S_CONV = NOB * OCB * CONV_PITCH;
 constexpr int S_ALL = S_IN > S_CONV ? S_IN : S_CONV;
 
 __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
@@ -44,7 +45,7 @@ __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
     l = __builtin_bit_cast(unsigned, vl);
 }
 
-__global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x, const uint16_t *__restrict__ w3,
+__global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x, const uint16_t *__restrict__ w3,
                                                     const float *__restrict__ oscale, const float *__restrict__ scale,
                                                     const float *__restrict__ shift, int h, int wd, float *__restrict__ y,
                                                     int64_t y_bs, const float *__restrict__ in_range,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x,
     const int tiles_x = (pw + PTW - 1) / PTW;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x % tiles_x;
     const int64_t img = blockIdx.y;
-    const int oc0 = blockIdx.z * OCB;
+    const int oc0 = 0;
     const int py0 = tile_y * PTH, px0 = tile_x * PTW;
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv row/col of the tile
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input row/col of the patch
@@ -98,17 +99,26 @@ __global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x,
         const int r = p / CTW, q = p % CTW;
         xbase[t] = 2 * r * PH + q;                       // + row offset of (c, ky) + j (+ PLANE for odd kx)
     }
-    // A fragments: w3[oc block][step][term][oc = n][16 k], this lane's 16 bytes at k = 8 half
-    const uint16_t *wp = w3 + ((int64_t)blockIdx.z * NSTEP * 2 * OCB + n) * 16 + 8 * half;
-    f32x16 acc[2];
+    // A fragments: w3[oc block][step][term][oc = n][16 k], this lane's 16 bytes at k = 8 half.  Both channel blocks run
+    // in this workgroup: the B fragment of a (pixel block, step) is split ONCE (the ~40 VALU instructions of the split,
+    // not the three MFMAs of one block, bounded the one-block version) and feeds 2 x 3 MFMAs.
+    const uint16_t *wp = w3 + (int64_t)n * 16 + 8 * half;
+    constexpr int WBLK = NSTEP * 2 * OCB * 16;           // fp16 elements of one channel block's weights
+    f32x16 acc[2][NOB];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int b = 0; b < NOB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-        const f16x8 ah = *reinterpret_cast<const f16x8 *>(wp + (s * 2 + 0) * OCB * 16);
-        const f16x8 al = *reinterpret_cast<const f16x8 *>(wp + (s * 2 + 1) * OCB * 16);
+        f16x8 ah[NOB], al[NOB];
+#pragma unroll
+        for (int b = 0; b < NOB; ++b) {
+            ah[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 0) * OCB * 16);
+            al[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 1) * OCB * 16);
+        }
         // this k-group's (c, ky) row: 2 s + half, row 21 (zero weights) re-reads row 20
         const int rho0 = 2 * s, rho1 = 2 * s + 1 < 21 ? 2 * s + 1 : 20;
         const int ro0 = ((rho0 / 7) * ITH + rho0 % 7) * PH, ro1 = ((rho1 / 7) * ITH + rho1 % 7) * PH;
@@ -124,12 +134,15 @@ __global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x,
             split2(po[0], po[1], th, tl); bh[2] = th; bl[2] = tl;
             split2(po[2], po[3], th, tl); bh[3] = th; bl[3] = tl;
             const f16x8 xh = __builtin_bit_cast(f16x8, bh), xl = __builtin_bit_cast(f16x8, bl);
-            f32x16 c = acc[t];
-            // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, c, 0, 0, 0);
-            acc[t] = c;
+#pragma unroll
+            for (int b = 0; b < NOB; ++b) {
+                f32x16 c = acc[t][b];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[b], xh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], xl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], xh, c, 0, 0, 0);
+                acc[t][b] = c;
+            }
         }
     }
 
@@ -144,11 +157,13 @@ __global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x,
             // outside the conv map = pool padding; 0 never wins over a relu output
             const bool inside = cy >= 0 && cy < ch && cx >= 0 && cx < cw;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
-                const float v = fmaxf(fmaf(acc[t][r] * (oscale[oc0 + oc] * x_inv), scale[oc0 + oc], shift[oc0 + oc]), 0.0f);
-                s_conv[oc * CONV_PITCH + p] = inside ? v : 0.0f;
-            }
+            for (int b = 0; b < NOB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = b * OCB + 8 * (r >> 2) + (r & 3) + 4 * half;
+                    const float v = fmaxf(fmaf(acc[t][b][r] * (oscale[oc] * x_inv), scale[oc], shift[oc]), 0.0f);
+                    s_conv[oc * CONV_PITCH + p] = inside ? v : 0.0f;
+                }
         }
     }
     __syncthreads();
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void k_stem_h2(const float *__restrict__ x,
     // ---- max-pool 3x3 / 2: only the pooled map goes to HBM ----------------------------------------
     float *yi = y + img * y_bs + oc0 * (int64_t)ph * pw;   // y_bs: batch stride (the dense block's buffer)
     float vmax = 0.f;
-    for (int i = threadIdx.x; i < OCB * PTH * 8; i += 256) {
+    for (int i = threadIdx.x; i < NOB * OCB * PTH * 8; i += 256) {
         const int oc = i / (PTH * 8), r = (i / 8) % PTH, q = i % 8;
         const int py = py0 + r, px = px0 + q;
         if (q < PTW && py < ph && px < pw) {
@@ -186,7 +201,7 @@ hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscal
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stem_h2, dim3((unsigned)tiles, (unsigned)n, 64 / OCB), dim3(256), lds, st, x, w2, oscale, scale, shift,
+    hipLaunchKernelGGL(k_stem_h2, dim3((unsigned)tiles, (unsigned)n, 1), dim3(256), lds, st, x, w2, oscale, scale, shift,
                        h, wd, y, y_bs, in_range, reinterpret_cast<unsigned *>(out_range));
     return hipGetLastError();
 }
