@@ -37,8 +37,8 @@ constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage 
 constexpr int PLANE_B = CP * KC * 2;
 constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // 16 KiB
 
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS>
-__global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, bool POOL>
+__global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w2,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
                                                        float *__restrict__ y, int64_t ybs,
                                                        const float *__restrict__ in_amax, float in_ks, float in_kb,
                                                        unsigned *__restrict__ out_amax, float y_ks, float y_kb,
-                                                       float *__restrict__ y_inv_out) {
+                                                       float *__restrict__ y_inv_out, int pool_w) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ float sBias[CM], sOsc[CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -74,12 +74,18 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
     // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
     const int b_px = threadIdx.x & 127;
     const int b_kg = wave >> 1;
+    // POOL (transitions): x is the un-pooled map [.., 2 ph, 2 pw]; a staged value is the average of relu(bn(.)) over the 2 x 2
+    // input pixels of output pixel (oy, ox) -- the norm + relu + avgpool pass and its pooled tensor disappear
+    const int64_t in_hw = POOL ? 4 * (int64_t)hw : (int64_t)hw;       // channel stride of x
     int64_t b_off = 0;
     {
         const int64_t pp = p0 + b_px;
-        if (pp < total) b_off = (pp / hw) * xbs + (pp % hw);
+        if (pp < total) {
+            const int64_t o = pp % hw;
+            b_off = (pp / hw) * xbs + (POOL ? (2 * (o / pool_w)) * (int64_t)(2 * pool_w) + 2 * (o % pool_w) : o);
+        }
     }
-    const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * hw;
+    const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * in_hw;
     const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + term * PLANE_B
     // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
     // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
@@ -99,14 +105,25 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
     // TWO register sets: the activation loads of stage kt + 2 are issued while stage kt computes and stage kt + 1
     // waits in the other set.  With one set a workgroup has 8 KiB of HBM reads in flight (32 KiB per CU at four
     // workgroups): by Little's law that caps the layer near 4 TB/s, which is where the one-set kernel sat.
-    float ra[8], rb[8], sca[8], sha[8], scb[8], shb[8];
-    auto load = [&](int kt, float (&r)[8], float (&rsc)[8], float (&rsh)[8]) {
+    constexpr int NR = POOL ? 32 : 8;                   // raw values per thread and stage
+    float ra[NR], rb[NR], sca[8], sha[8], scb[8], shb[8];
+    auto load = [&](int kt, float (&r)[NR], float (&rsc)[8], float (&rsh)[8]) {
+        if constexpr (POOL) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float *pj = xsrc + ((int64_t)kt * KC + j) * in_hw;
+                const f32x2 t0 = *reinterpret_cast<const f32x2 *>(pj);
+                const f32x2 t1 = *reinterpret_cast<const f32x2 *>(pj + 2 * pool_w);
+                r[4 * j] = t0[0]; r[4 * j + 1] = t0[1]; r[4 * j + 2] = t1[0]; r[4 * j + 3] = t1[1];
+            }
+        } else {
 #pragma unroll
 #ifdef MIRX_C1H2_NT_LOADS      // experiment (measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images): `nt` activation loads so that the weights stay L2-resident
         for (int j = 0; j < 8; ++j) r[j] = __builtin_nontemporal_load(&xsrc[((int64_t)kt * KC + j) * hw]);
 #else
         for (int j = 0; j < 8; ++j) r[j] = xsrc[((int64_t)kt * KC + j) * hw];
 #endif
+        }
         if (PROLOGUE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -115,16 +132,28 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
             }
         }
     };
-    auto store = [&](int buf, const float (&r)[8], const float (&rsc)[8], const float (&rsh)[8]) {
+    auto store = [&](int buf, const float (&r)[NR], const float (&rsc)[8], const float (&rsh)[8]) {
         char *sb = sm + buf * STAGE;
         // two fp16 terms of each (scaled) value, two values at a time (round to nearest even)
         u32x4 ph, pl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x2 v = {r[2 * j], r[2 * j + 1]};
-            if (PROLOGUE) {
-                v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
-                v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
+            f32x2 v;
+            if constexpr (POOL) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * j + e;
+                    const float s0 = fmaxf(fmaf(r[4 * c], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[4 * c + 1], rsc[c], rsh[c]), 0.f);
+                    const float s1 = fmaxf(fmaf(r[4 * c + 2], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[4 * c + 3], rsc[c], rsh[c]), 0.f);
+                    v[e] = (s0 + s1) * 0.25f;
+                }
+            } else {
+                v[0] = r[2 * j];
+                v[1] = r[2 * j + 1];
+                if (PROLOGUE) {
+                    v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
+                    v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
+                }
             }
             v = v * x_scale;
             const f16x2 h = __builtin_convertvector(v, f16x2);
@@ -161,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
         sOsc[threadIdx.x] = oscale[co0 + threadIdx.x] * x_inv;
     }
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
-    auto stage = [&](int kt, int cur, float (&rnext)[8], float (&scn)[8], float (&shn)[8], const float (&rstore)[8],
+    auto stage = [&](int kt, int cur, float (&rnext)[NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NR],
                      const float (&scs)[8], const float (&shs)[8]) {
         // stage kt visible: this wave's weight DMA of stage kt has landed.  vmcnt(0), NOT a counted wait: the two DMA
         // pieces are older than the 8 activation loads issued behind them, and `vmcnt(8)` was tried to keep those loads
@@ -276,28 +305,31 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_h2(const float *__restrict__
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, hipStream_t st) {
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM || !oscale) return hipErrorInvalidValue;
     const bool yterms = y_inv_out != nullptr;
-    if (yterms && (cout != CM || !relu_out || !scale)) return hipErrorInvalidValue;
+    if (yterms && (cout != CM || !relu_out || !scale || pool_w)) return hipErrorInvalidValue;
+    if (pool_w && (!scale || relu_out || hw % pool_w)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)STAGE;
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
-#define MIRX_H2C(P, R, T)                                                                                  \
+#define MIRX_H2C(P, R, T, L)                                                                               \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T>),          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, L>),       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
-                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out);         \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, L>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, pool_w); \
     }
-    if (yterms) {
-        MIRX_H2C(true, true, true)
+    if (pool_w) {
+        MIRX_H2C(true, false, false, true)
+    } else if (yterms) {
+        MIRX_H2C(true, true, true, false)
     } else if (scale) {
-        if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)
+        if (relu_out) MIRX_H2C(true, true, false, false) else MIRX_H2C(true, false, false, false)
     } else {
-        if (relu_out) MIRX_H2C(false, true, false) else MIRX_H2C(false, false, false)
+        if (relu_out) MIRX_H2C(false, true, false, false) else MIRX_H2C(false, false, false, false)
     }
 #undef MIRX_H2C
     return hipGetLastError();

@@ -731,8 +731,24 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                "conv1x1_split2h: in_ks / in_kb are non-negative; without range slots in_kb is the bound itself");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
                                reinterpret_cast<const uint16_t *>(w2), oscale, bias_or_null, n, hw, cout, relu_out, y,
-                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr,
+                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr, 0,
                                reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale,
+                                                 const float *shift, const void *w2, const float *oscale, int64_t n, int h,
+                                                 int w, int cout, float *y, int64_t y_batch_stride, const float *in_range,
+                                                 float in_ks, float in_kb, float *out_range_or_null, void *stream) {
+    MIRX_CHECK(n >= 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "transition: H and W must be even");
+    MIRX_CHECK(cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0, "transition: cin % 16 == 0, cout % 128 == 0");
+    MIRX_CHECK(n == 0 || (x && scale && shift && w2 && oscale && y && in_range), "transition: null buffer");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * h * w && y_batch_stride >= (int64_t)cout * (h / 2) * (w / 2),
+               "transition: batch stride too small");
+    MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f, "transition: bounds are non-negative");
+    MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale, shift, reinterpret_cast<const uint16_t *>(w2), oscale, nullptr, n,
+                               (h / 2) * (w / 2), cout, 0, y, y_batch_stride, in_range, in_ks, in_kb, out_range_or_null, 0.f,
+                               0.f, nullptr, w / 2, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
@@ -747,7 +763,7 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
     MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && y_ks >= 0.f && y_kb >= 0.f, "conv1x1_split2h_terms: bounds are non-negative");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1, shift1, reinterpret_cast<const uint16_t *>(w2), oscale, bias, n,
                                hw, 128, 1, reinterpret_cast<float *>(y_terms), 0, in_range, in_ks, in_kb, nullptr, y_ks, y_kb,
-                               y_inv_out, reinterpret_cast<hipStream_t>(stream)));
+                               y_inv_out, 0, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

@@ -78,7 +78,7 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, hipStream_t st);
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, hipStream_t st);
 
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,

@@ -209,6 +209,15 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                                  int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
                                  float *out_range_or_null, void *stream);
 
+/* DenseNet transition (norm -> relu -> conv 1x1 -> avgpool 2x2, torchvision _Transition) in ONE launch: the average pool is
+ * moved in front of the (linear) convolution and into its staging -- a staged value is the mean of relu(bn(x)) over the
+ * 2 x 2 input pixels -- so neither the normalised map nor the pooled map exists in memory.  x = [n, >= cin, h, w] with
+ * batch stride x_batch_stride, y = [n, cout, h/2, w/2] at y_batch_stride (the channel prefix of the next block's buffer);
+ * two fp16 terms, ranges as mirx_conv1x1_bn_relu_split2h (in_ks / in_kb = max |scale| / max |shift|). */
+int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale,
+                                                 const float *shift, const void *w2, const float *oscale, int64_t n, int h,
+                                                 int w, int cout, float *y, int64_t y_batch_stride, const float *in_range,
+                                                 float in_ks, float in_kb, float *out_range_or_null, void *stream);
 /*
  * The dense layer with the 128-channel bottleneck handed over ALREADY SPLIT into its two fp16 terms (same bytes as fp32,
  * but the 3x3 conv then stages it by LDS DMA alone -- no register prefetch, no split, no LDS stores -- and the 1x1 conv

@@ -363,6 +363,49 @@ def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,h,w,n,mag", [(256, 56, 56, 2, 1.0), (512, 28, 28, 3, 30.0), (1024, 14, 14, 5, 1e-2), (64, 6, 10, 3, 1.0)])
+def test_fused_transition_matches_float64(cin, h, w, n, mag):
+    """mirx_transition_bn_relu_pool_conv1x1_split2h (norm + relu + avgpool inside the 1x1 conv's staging) against a
+    float64 restatement in the REFERENCE's order (norm, relu, conv, pool: torchvision _Transition): fp32-grade, output
+    written as a channel prefix, range published, a ragged last tile (n * h/2 * w/2 not a multiple of 128) included."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(cin + h)
+    cout = max(cin // 2, 128)
+    ctot = cin + 16
+    buf = torch.randn(n, ctot, h, w, generator=g, device=dev) * mag
+    wt = torch.randn(cout, cin, generator=g, device=dev) / cin ** 0.5
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3 * mag
+    w2, osc = _split2h_weights(wt)
+    slots_in = torch.zeros(64, device=dev)
+    slots_in[5] = float(buf[:, :cin].abs().max())
+    slots_out = torch.zeros(64, device=dev)
+    hw2 = (h // 2) * (w // 2)
+    ybuf = torch.full((n, cout + 8, h // 2, w // 2), -5.0, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    args = (vp(buf), ctot * h * w, cin, vp(sc), vp(sh), vp(w2), vp(osc), n, h, w, cout, vp(ybuf), (cout + 8) * hw2, vp(slots_in),
+            float(sc.abs().max()), float(sh.abs().max()))
+    _lib.check(lib.mirx_transition_bn_relu_pool_conv1x1_split2h(*args, vp(slots_out), None), "transition")
+    torch.cuda.synchronize()
+    act = torch.relu(buf[:, :cin].double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    want = torch.nn.functional.avg_pool2d(torch.einsum("oc,bchw->bohw", wt.double(), act), 2)
+    y = ybuf[:, :cout]
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(mag, float(want.abs().max())), err
+    assert bool((ybuf[:, cout:] == -5.0).all())
+    assert float(slots_out.max()) == float(y.abs().max())
+    slots_in[0] = float("nan")
+    _lib.check(lib.mirx_transition_bn_relu_pool_conv1x1_split2h(*args, None, None), "transition")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(y).all())
+    assert lib.mirx_transition_bn_relu_pool_conv1x1_split2h(*(args[:9] + (w + 1,) + args[10:]), None, None) != 0   # odd width
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("side,batch,mag", [(56, 3, 1.7), (28, 5, 60.0), (14, 9, 1e-3), (14, 1, 1.7)])
 def test_direct_split2h_conv3x3_matches_direct_conv(side, batch, mag):
     """mirx_conv3x3_direct_split2h_nchw (implicit GEMM on two fp16 terms per operand; input range from range slots,
