@@ -303,8 +303,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int half = lane >> 5, n = lane & 31;
-    const int strip = blockIdx.x;
-    const int64_t img = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin in linear order, and each XCD has its own L2: with (strip, image) =
+    // blockIdx the neighbouring strips of an image -- which share two halo rows each -- would sit on different XCDs and
+    // every halo row would cross the fabric twice (1.5x the map at R = 4).  Re-deal so that XCD x walks images x, x + 8, ..
+    // strip by strip: the halo of a strip is then in the L2 its neighbour just filled (+3 %).  (Any bijection is correct.)
+    int strip = blockIdx.x;
+    int64_t img = blockIdx.y;
+    {
+        const unsigned nstrip = gridDim.x, lin = blockIdx.x + nstrip * blockIdx.y, full = gridDim.y & ~7u;
+        if (lin < nstrip * full) {
+            const unsigned j = lin >> 3;
+            strip = (int)(j % nstrip);
+            img = (int64_t)(j / nstrip) * 8 + (lin & 7);
+        }
+    }
     const int oy0 = strip * R;                                // first output row of the strip
     constexpr unsigned IMG_BYTES = 16u * W * W * 32u;        // 8 groups x 2 terms x W*W pixels x 32 B
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(yt + img * (int64_t)(IMG_BYTES / 2)), 0,

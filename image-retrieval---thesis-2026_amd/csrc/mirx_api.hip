@@ -773,8 +773,18 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
     MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms: side must be 56, 28 or 14");
     MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
     MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_terms: output batch stride too small");
+    MIRX_CHECK((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0,
+               "conv3x3_terms: out must be 16-byte aligned and the batch stride a multiple of 4 floats");
+#ifndef MIRX_CONV3X3_TERMS_MFMA
+#define MIRX_CONV3X3_TERMS_MFMA 32   // 16: k_conv3x3_d2q on v_mfma_f32_16x16x32_f16 (the A/B arm: higher clock, same time)
+#endif
+#if MIRX_CONV3X3_TERMS_MFMA == 16
+    MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                side, out, out_batch_stride, y_inv, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+#else
     MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
                                 side, out, out_batch_stride, y_inv, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+#endif
     return MIRX_OK;
 }
 

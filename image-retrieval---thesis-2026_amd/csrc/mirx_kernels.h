@@ -117,6 +117,9 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
 // k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st);
+// k_conv3x3_d2q.hip: the same on v_mfma_f32_16x16x32_f16 (A/B arm, -DMIRX_CONV3X3_TERMS_MFMA=16; `out` 16-byte aligned)
+hipError_t launch_conv3x3_d2q(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

@@ -40,6 +40,11 @@ def main():
             kinds["direct3"] = lambda: lib.mirx_conv3x3_direct_split3_nchw(vp(x), vp(w3), a.batch, side, vp(out), bs, None)
             kinds["direct2h"] = lambda: lib.mirx_conv3x3_direct_split2h_nchw(vp(x), vp(w2), vp(osc), a.batch, side, vp(out), bs,
                                                                             vp(rin), vp(rout), None)
+            # terms path: the bottleneck pre-split into fp16 terms [n][8][2][hw][16] (timing only: random planes)
+            yt = (torch.randn(a.batch, 8, 2, side * side, 16, generator=g, device=dev) * 100).half()
+            yinv = torch.full((1,), 2.0 ** -7, device=dev)
+            kinds["terms"] = lambda: lib.mirx_conv3x3_direct_terms_nchw(vp(yt), vp(w2), vp(osc), a.batch, side, vp(out), bs,
+                                                                        vp(yinv), vp(rout), None)
         for name, fn in kinds.items():
             for it in range(a.iters + 2):
                 if it == 2:

@@ -36,6 +36,27 @@ def main():
         print(f"{name:44s} {100.0 * c / max(r, 1):7.0f} MHz  (probe window {r / 100.0:.0f} us)", flush=True)
 
     measure("idle (probe alone)", lambda: None, ms=2)
+    if "--h2" in sys.argv:                                              # round 2: the two-fp16-term DenseNet kernels only
+        from mirx.model import _conv3x3_weights_split2h, _split2h_weights
+        g = torch.Generator(device=dev).manual_seed(0)
+        w2, osc = _conv3x3_weights_split2h(torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05)
+        yinv = torch.full((1,), 2.0 ** -7, device=dev)
+        for sd in (56, 28):
+            yt = (torch.randn(1024, 8, 2, sd * sd, 16, generator=g, device=dev) * 100).half()
+            oo = torch.empty(1024, 32, sd, sd, device=dev)
+            measure(f"k_conv3x3_d2p<{sd}> (1024 images)", lambda: _lib.check(lib.mirx_conv3x3_direct_terms_nchw(
+                vp(yt), vp(w2), vp(osc), 1024, sd, vp(oo), 32 * sd * sd, vp(yinv), None, None), "c"))
+        cin, hw = 256, 3136
+        xb = torch.randn(1024, cin, hw, generator=g, device=dev)
+        w1, o1 = _split2h_weights(torch.randn(128, cin, generator=g, device=dev) / 16)
+        sc, sh, bias = torch.ones(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(128, device=dev)
+        rng = torch.zeros(64, device=dev)
+        rng[0] = 6.0
+        ytt = torch.empty(1024, 8, 2, hw, 16, dtype=torch.float16, device=dev)
+        measure("k_conv1x1_h2 terms 256 -> 128 @56 (1024)", lambda: _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(
+            vp(xb), cin * hw, cin, vp(sc), vp(sh), vp(w1), vp(o1), vp(bias), 1024, hw, vp(ytt), vp(rng), 1.0, 0.0, 16.0, 0.0,
+            vp(yinv), None), "c"))
+        return
     # distance GEMM: 8192 queries over 1M x 1024
     g = torch.Generator(device=dev).manual_seed(0)
     gal = torch.nn.functional.normalize(torch.randn(1_000_000, 1024, generator=g, device=dev), dim=1)
