@@ -93,13 +93,37 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)), 0, nk * (2 * CM * KC * 2), 0x00020000);
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-    auto dma_w = [&](int kt, int buf) {
+    [[maybe_unused]] auto dma_w = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wave + 4 * i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE + piece * 1024), 16, w_voff,
                                                      kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
         }
+    };
+
+#ifndef MIRX_C1H2_W_DMA
+#define MIRX_C1H2_W_DMA 1      // 0: weights through registers (plain loads + ds_write_b128), the A/B arm
+#endif
+    // A/B arm, weights through registers: thread t copies 16-byte chunk (row t / 2, slot t & 1) of both term planes.  With plain
+    // loads only, hipcc's own counted s_waitcnt (vmcnt(19) .. vmcnt(10) in the ISA) keeps the loads of stage kt + 2 in flight
+    // across the barrier of stage kt + 1 -- two stages of reads per workgroup instead of the one the DMA version can have
+    // (it must drain with vmcnt(0), see below).  Measured: isolated layers at 1024 images 2-4 % faster on the 28 / 14 maps,
+    // 6 % slower on the 7 maps; the whole forward (B = 4096, two streams) 1.2 % SLOWER (42.7 vs 43.2 k img/s, same box) --
+    // the layers are not latency-bound either.  A build with one MFMA per product instead of three (MIRX_C1H2_EXP_ONE_MFMA)
+    // gains 5-7 %: not matrix-bound.  What is left is the memory system itself at 3.4-4.9 TB/s with a 1.25 GHz shader clock.
+    const int wq_row = threadIdx.x >> 1, wq_slot = threadIdx.x & 1;
+    const char *wsrc = reinterpret_cast<const char *>(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)) + wq_row * 32 +
+                       ((wq_slot ^ ((wq_row >> 3) & 1)) << 4);
+    const int wq_lds = wq_row * 32 + wq_slot * 16;
+    u32x4 wa[2], wb[2];
+    [[maybe_unused]] auto load_w = [&](int kt, u32x4 (&w)[2]) {
+        w[0] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (2 * CM * KC * 2));
+        w[1] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (2 * CM * KC * 2) + CM * KC * 2);
+    };
+    [[maybe_unused]] auto store_w = [&](int buf, const u32x4 (&w)[2]) {
+        *reinterpret_cast<u32x4 *>(sm + buf * STAGE + wq_lds) = w[0];
+        *reinterpret_cast<u32x4 *>(sm + buf * STAGE + PLANE_A + wq_lds) = w[1];
     };
 
     // TWO register sets: the activation loads of stage kt + 2 are issued while stage kt computes and stage kt + 1
@@ -190,17 +214,22 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         sOsc[threadIdx.x] = oscale[co0 + threadIdx.x] * x_inv;
     }
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
-    auto stage = [&](int kt, int cur, float (&rnext)[NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NR],
-                     const float (&scs)[8], const float (&shs)[8]) {
+    auto stage = [&](int kt, int cur, float (&rnext)[NR], float (&scn)[8], float (&shn)[8], u32x4 (&wnext)[2],
+                     const float (&rstore)[NR], const float (&scs)[8], const float (&shs)[8], const u32x4 (&wstore)[2]) {
         // stage kt visible: this wave's weight DMA of stage kt has landed.  vmcnt(0), NOT a counted wait: the two DMA
         // pieces are older than the 8 activation loads issued behind them, and `vmcnt(8)` was tried to keep those loads
         // in flight across the barrier -- it produced state-dependent results (embeddings off by 2e-5 once the caches
         // were warm: the LDS-DMA pieces were still landing when the count had already dropped to 8), i.e. LDS-DMA and
         // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
         // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
+#if MIRX_C1H2_W_DMA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
+#else
+        __syncthreads();
+        load_w(kt + 2 < nk ? kt + 2 : nk - 1, wnext);
+#endif
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
         const char *sb = sm + cur * STAGE;
@@ -218,23 +247,38 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
             for (int ni = 0; ni < 2; ++ni) {
                 f32x16 c = acc[mi][ni];
                 // smallest terms first
+#ifndef MIRX_C1H2_EXP_ONE_MFMA          // diagnostic build (wrong results, timing only): one MFMA per product block
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][1], b[ni][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][1], c, 0, 0, 0);
+#endif
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], c, 0, 0, 0);
                 acc[mi][ni] = c;
             }
         store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
+#if !MIRX_C1H2_W_DMA
+        store_w(cur ^ 1, wstore);
+#endif
     };
+#if MIRX_C1H2_W_DMA
     dma_w(0, 0);
+#else
+    load_w(0, wa);
+#endif
     load(0, ra, sca, sha);
+#if !MIRX_C1H2_W_DMA
+    load_w(nk > 1 ? 1 : 0, wb);
+#endif
     load(nk > 1 ? 1 : 0, rb, scb, shb);
     store(0, ra, sca, sha);
+#if !MIRX_C1H2_W_DMA
+    store_w(0, wa);
+#endif
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        stage(kt, 0, ra, sca, sha, rb, scb, shb);
-        stage(kt + 1, 1, rb, scb, shb, ra, sca, sha);
+        stage(kt, 0, ra, sca, sha, wa, rb, scb, shb, wb);
+        stage(kt + 1, 1, rb, scb, shb, wb, ra, sca, sha, wa);
     }
-    if (kt < nk) stage(kt, 0, ra, sca, sha, rb, scb, shb);
+    if (kt < nk) stage(kt, 0, ra, sca, sha, wa, rb, scb, shb, wb);
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 64 wn + 32 ni + (lane & 31)
