@@ -60,6 +60,8 @@ SYMBOLS = {
     "mirx_linear_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_linear_split3": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "mirx_linear_split2h_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,
+                                        _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),

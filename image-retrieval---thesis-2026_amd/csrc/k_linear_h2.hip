@@ -44,8 +44,17 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                                                       const float *__restrict__ bias, int n, const float *res,
                                                       const float *__restrict__ gamma, float *y, int ntn,
                                                       int64_t total_tiles, int64_t per_xcd, int tpi, float x_scale,
-                                                      float out_scale) {
+                                                      float out_scale, const float *__restrict__ xb_dev) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
+    // xb_dev: the input's bound lives (partly) on the device -- |x * gamma| <= x_scale * xb_dev[0] with `x_scale` the host's
+    // bound on |x| and xb_dev[0] the largest |gamma| (ConvNeXt GRN scale, computed per forward); the kernel derives the
+    // power-of-two scales itself and `out_scale` arrives as 1 / w_scale.  A non-finite bound turns every output into NaN.
+    if (xb_dev) {
+        float xs, xi;
+        range_scales(x_scale * xb_dev[0], xs, xi);
+        x_scale = xs;
+        out_scale *= xi;
+    }
     const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (tile >= total_tiles) return;
     const int tn = (int)(tile % ntn);
@@ -95,7 +104,12 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
         u32x4 ph, pl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x2 v = {r[j >> 1][2 * (j & 1)] * x_scale, r[j >> 1][2 * (j & 1) + 1] * x_scale};
+            f32x2 v = {r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
+            if (GRN) {
+                v[0] *= sc[j >> 1][2 * (j & 1)];
+                v[1] *= sc[j >> 1][2 * (j & 1) + 1];
+            }
+            v = v * x_scale;
             const bf16x2 h = __builtin_convertvector(v, bf16x2);
             const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
             const bf16x2 l = __builtin_convertvector(r1, bf16x2);
@@ -142,7 +156,8 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 f32x16 c = acc[mi][ni];
                 // smallest terms first; NCHW: outputs on the MFMA rows, tokens on the lanes
 #define MIRX_L3_MFMA(TA, TB)                                                                               \
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][TA], b[ni][TB], c, 0, 0, 0);
+    c = NCHW ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][TB], a[mi][TA], c, 0, 0, 0)                    \
+             : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][TA], b[ni][TB], c, 0, 0, 0);
                 MIRX_L3_MFMA(1, 0)
                 MIRX_L3_MFMA(0, 1)
                 MIRX_L3_MFMA(0, 0)
@@ -232,7 +247,8 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
 }  // namespace
 
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
-                            const float *res, const float *gamma, float x_scale, float out_scale, float *y, hipStream_t st) {
+                            const float *res, const float *gamma, float x_scale, float out_scale, float *y,
+                            int tokens_per_image, const float *xb_dev, hipStream_t st) {
     if (m <= 0) return hipSuccess;
     if (k % KC || n < 1 || act < 0 || act > 2) return hipErrorInvalidValue;
     const int ntn = (n + TN - 1) / TN;                 // w2 holds ntn * 128 rows, zero beyond n
@@ -241,19 +257,27 @@ hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2
     if (per_xcd * 8 > 0x7fffffff) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(per_xcd * 8));
     const size_t lds = 2 * (size_t)STAGE;
-#define MIRX_H2(A, R)                                                                                      \
+#define MIRX_H2(A, R, C, G)                                                                                \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_h2<A, R, false, false>), \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_h2<A, R, C, G>),        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_linear_h2<A, R, false, false>), grid, dim3(256), lds, st, x, m, k, w2, bias, n, res, \
-                           gamma, y, ntn, total, per_xcd, 0, x_scale, out_scale);                          \
+        hipLaunchKernelGGL((k_linear_h2<A, R, C, G>), grid, dim3(256), lds, st, x, m, k, w2, bias, n, res, gamma, y, ntn, \
+                           total, per_xcd, tokens_per_image, x_scale, out_scale, xb_dev);                  \
     }
-    if (res) {
-        if (act == 2) return hipErrorInvalidValue;
-        if (act) MIRX_H2(1, true) else MIRX_H2(0, true)
+    if (tokens_per_image > 0) {                       // ConvNeXt block tail / downsample: `gamma` = GRN input scale [images][k] or null
+        if (act) return hipErrorInvalidValue;
+        if (gamma) {
+            if (res) MIRX_H2(0, true, true, true) else MIRX_H2(0, false, true, true)
+        } else {
+            if (res) MIRX_H2(0, true, true, false) else MIRX_H2(0, false, true, false)
+        }
+    } else if (res) {
+        if (act == 2 || xb_dev) return hipErrorInvalidValue;
+        if (act) MIRX_H2(1, true, false, false) else MIRX_H2(0, true, false, false)
     } else {
-        if (act == 2) MIRX_H2(2, false) else if (act) MIRX_H2(1, false) else MIRX_H2(0, false)
+        if (xb_dev) return hipErrorInvalidValue;
+        if (act == 2) MIRX_H2(2, false, false, false) else if (act) MIRX_H2(1, false, false, false) else MIRX_H2(0, false, false, false)
     }
 #undef MIRX_H2
     return hipGetLastError();

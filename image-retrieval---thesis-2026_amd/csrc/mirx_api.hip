@@ -6,6 +6,7 @@
 //   -> exact scan (fp64 score tiles + row top-k) for the queries the guard rejected.
 // The only host<->device synchronisation is one read of the rejected-query count.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <mutex>
@@ -810,7 +811,35 @@ int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const 
     MIRX_CHECK(x != y, "linear_split2h: y may alias the residual, not the input");
     MIRX_CHECK(x_scale > 0.f && out_scale > 0.f, "linear_split2h: scales must be positive powers of two");
     MIRX_HIP(launch_linear_h2(x, m, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, act, residual_or_null,
-                              gamma_or_null, x_scale, out_scale, y, reinterpret_cast<hipStream_t>(stream)));
+                              gamma_or_null, x_scale, out_scale, y, 0, nullptr, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                             const float *bias_or_null, int n, const float *residual_or_null,
+                             const float *input_scale_or_null, float x_bound, const float *input_scale_max_or_null,
+                             float w_inv, float *y, void *stream) {
+    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 1,
+               "linear_split2h_nchw: k must be a multiple of 16");
+    MIRX_CHECK(n_img == 0 || (x && w2 && y), "linear_split2h_nchw: null buffer");
+    MIRX_CHECK(x != y, "linear_split2h_nchw: y may alias the residual, not the input");
+    MIRX_CHECK(x_bound > 0.f && w_inv > 0.f, "linear_split2h_nchw: x_bound and w_inv must be positive");
+    MIRX_CHECK(!input_scale_or_null == !input_scale_max_or_null,
+               "linear_split2h_nchw: an input scale needs the device scalar that bounds it (and only then)");
+    if (input_scale_max_or_null) {
+        // the kernel derives 2^s from x_bound * input_scale_max[0]
+        MIRX_HIP(launch_linear_h2(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, 0,
+                                  residual_or_null, input_scale_or_null, x_bound, w_inv, y, tokens_per_image,
+                                  input_scale_max_or_null, reinterpret_cast<hipStream_t>(stream)));
+    } else {
+        int e = 0;                                     // x_bound * 2^s in [2^14, 2^15)
+        (void)frexpf(x_bound, &e);                     // x_bound = f * 2^e, f in [0.5, 1)
+        const float xs = ldexpf(1.f, 15 - e);
+        MIRX_CHECK(std::isfinite(x_bound) && std::isfinite(xs) && xs > 0.f, "linear_split2h_nchw: x_bound out of range");
+        MIRX_HIP(launch_linear_h2(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, 0,
+                                  residual_or_null, nullptr, xs, w_inv / xs, y, tokens_per_image, nullptr,
+                                  reinterpret_cast<hipStream_t>(stream)));
+    }
     return MIRX_OK;
 }
 

@@ -82,7 +82,8 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
 
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
-                            const float *res, const float *gamma, float x_scale, float out_scale, float *y, hipStream_t st);
+                            const float *res, const float *gamma, float x_scale, float out_scale, float *y,
+                            int tokens_per_image, const float *xb_dev, hipStream_t st);
 
 // ---- k_linear_s3.hip ---------------------------------------------------------------------
 // tokens_per_image == 0: y / res are [m][n]; > 0: token t is pixel t % tpi of image t / tpi and y / res are NCHW

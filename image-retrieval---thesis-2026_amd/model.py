@@ -672,6 +672,14 @@ def _conv_patch_tokens(conv, x, ln2d=None, nchw_out=False):
                    "mirx_patchify_nchw")
         if nchw_out:
             out = torch.empty((b, pl.out_features, gh, gw), dtype=torch.float32, device=x.device)
+            bound = _layernorm_bound(ln2d) if ln2d is not None else float("inf")
+            if _linear_h2_ok(pl, rows, bound):                 # the rows are LayerNorm outputs: two fp16 terms
+                w2, ws = _linear_h2_weights(pl)
+                _lib.check(lib.mirx_linear_split2h_nchw(_ptr(rows), b, gh * gw, pl.in_features, _ptr(w2),
+                                                        _ptr(pl.bias) if pl.bias is not None else None, pl.out_features, None,
+                                                        None, float(bound), None, 1.0 / ws, _ptr(out), st),
+                           "mirx_linear_split2h_nchw")
+                return out
             _lib.check(lib.mirx_linear_split3_nchw(_ptr(rows), b, gh * gw, pl.in_features, _ptr(_linear_w3(pl)),
                                                    _ptr(pl.bias) if pl.bias is not None else None, pl.out_features, None, None,
                                                    _ptr(out), st), "mirx_linear_split3_nchw")
@@ -1011,9 +1019,20 @@ class _CnxBlock(nn.Module):
                                       gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
                 # GRN apply folded into the second Linear: the scale multiplies x while it is staged, the shift
                 # is constant per feature, so W (x s + b) + bias = W (x s) + (bias + W b)
-                _lib.check(lib.mirx_linear_split3_nchw(_ptr(hid), b, h * w, c4, _ptr(_linear_w3(mlp.fc2)),
-                                                       _ptr(self._fc2_bias_with_grn_shift()), c, _ptr(xc), _ptr(scale),
-                                                       _ptr(out), st), "mirx_linear_split3_nchw")
+                hb = _linear_out_bound(self.norm, mlp.fc1)                 # |gelu(fc1(LN(.)))| <= |fc1(LN(.))| <= hb
+                if _linear_h2_ok(mlp.fc2, hid, hb):
+                    # two fp16 terms: |hid * scale| <= hb * max |scale|; the second factor is data, so it stays on the
+                    # device (one scalar) and the kernel derives its staging scale from it
+                    w2, ws = _linear_h2_weights(mlp.fc2)
+                    smax = scale.abs().amax().reshape(1)
+                    _lib.check(lib.mirx_linear_split2h_nchw(_ptr(hid), b, h * w, c4, _ptr(w2),
+                                                            _ptr(self._fc2_bias_with_grn_shift()), c, _ptr(xc), _ptr(scale),
+                                                            float(hb), _ptr(smax), 1.0 / ws, _ptr(out), st),
+                               "mirx_linear_split2h_nchw")
+                else:
+                    _lib.check(lib.mirx_linear_split3_nchw(_ptr(hid), b, h * w, c4, _ptr(_linear_w3(mlp.fc2)),
+                                                           _ptr(self._fc2_bias_with_grn_shift()), c, _ptr(xc), _ptr(scale),
+                                                           _ptr(out), st), "mirx_linear_split3_nchw")
             return out
         y = self.mlp(self.norm(y))
         return y.permute(0, 3, 1, 2) + x

@@ -336,6 +336,21 @@ int mirx_linear_split3_nchw(const float *x, int64_t n_img, int tokens_per_image,
                             const float *input_scale_or_null, float *y, void *stream);
 
 /*
+ * mirx_linear_split3_nchw on TWO fp16 terms per operand (mirx_linear_split2h's arithmetic) for inputs with a known bound:
+ *   |x[i, j]| <= x_bound for every element (host scalar, e.g. the provable bound of a Linear fed by a LayerNorm, through GELU);
+ *   input_scale (the GRN scale [n_img, k], multiplied into x while it is staged) comes with input_scale_max = device fp32[1]
+ *   holding max |input_scale| -- it is computed per forward, so the kernel reads it and derives the power-of-two staging
+ *   scale from x_bound * input_scale_max[0] itself (no host round trip; a non-finite bound makes every output NaN);
+ *   w2 / w_inv = mirx.model._linear_h2_weights (the two fp16 terms of W * w_scale, and 1 / w_scale).
+ * Reference: timm ConvNeXtBlock (mlp.fc2 after GRN, permute back, + shortcut) and the LayerNorm2d + 2x2/2 downsample conv,
+ * as used by the reference's model.py:87-118.
+ */
+int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                             const float *bias_or_null, int n, const float *residual_or_null,
+                             const float *input_scale_or_null, float x_bound, const float *input_scale_max_or_null,
+                             float w_inv, float *y, void *stream);
+
+/*
  * Global response normalisation of ConvNeXtV2 (timm GlobalResponseNorm, channels last) as two HBM passes:
  *   mirx_grn_norm_nhwc:  gx[b, c] = || x[b, :, c] ||_2              x = device fp32 [n, hw, c], gx = [n, c]
  *   mirx_grn_apply_nhwc: x[b, p, c] = x[b, p, c] * scale[b, c] + shift[c]  in place (c % 4 == 0)

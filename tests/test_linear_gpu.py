@@ -121,6 +121,57 @@ def test_linear_split3_nchw_matches_float64(n_img, tpi, k, n, use_res):
     assert err < 3e-6 * max(1.0, float(want.abs().max())), err
 
 
+@pytest.mark.parametrize("n_img,tpi,k,n,use_res", [(3, 144, 512, 128, True), (2, 577, 2048, 512, True),
+                                                   (5, 36, 64, 256, False), (1, 9216, 512, 128, True)])
+@pytest.mark.parametrize("xmax,loose", [(3.0, 1.0), (700.0, 64.0)])
+def test_linear_split2h_nchw_matches_float64(n_img, tpi, k, n, use_res, xmax, loose):
+    """mirx_linear_split2h_nchw (ConvNeXt block tail / downsample on two fp16 terms) against float64, without and with
+    the per-(image, feature) input scale whose maximum the kernel reads from the device; `loose`: the caller's bound
+    over-estimates max |x| by that factor (what a provable bound does) without costing accuracy."""
+    import mirx.model as mm
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n_img + tpi + k)
+    x = (torch.randn(n_img * tpi, k, generator=g).clamp(-4, 4) / 4.0 * xmax).to(dev)
+    lin = torch.nn.Linear(k, n).to(dev)
+    with torch.no_grad():
+        lin.bias.normal_()
+    w2, ws = mm._linear_h2_weights(lin)
+    w, b = lin.weight.detach(), lin.bias.detach()
+    res = torch.randn(n_img, n, tpi, generator=g).to(dev) if use_res else None
+    want = (x.double() @ w.double().t() + b.double()).reshape(n_img, tpi, n).permute(0, 2, 1)
+    if use_res:
+        want = want + res.double()
+    y = torch.full((n_img, n, tpi), float("nan"), device=dev)
+    _lib.check(lib.mirx_linear_split2h_nchw(_vp(x), n_img, tpi, k, _vp(w2), _vp(b), n, _vp(res), None, xmax * loose, None,
+                                            1.0 / ws, _vp(y), None), "mirx_linear_split2h_nchw")
+    torch.cuda.synchronize()
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+    # with the GRN factor folded into the staging; its maximum is device data
+    sc = (0.25 + 3.0 * torch.rand(n_img, k, generator=g)).to(dev)
+    smax = sc.abs().amax().reshape(1)
+    xs = (x.double().reshape(n_img, tpi, k) * sc.double()[:, None, :]).reshape(n_img * tpi, k)
+    want = (xs @ w.double().t() + b.double()).reshape(n_img, tpi, n).permute(0, 2, 1)
+    if use_res:
+        want = want + res.double()
+    y = torch.full((n_img, n, tpi), float("nan"), device=dev)
+    _lib.check(lib.mirx_linear_split2h_nchw(_vp(x), n_img, tpi, k, _vp(w2), _vp(b), n, _vp(res), _vp(sc), xmax * loose,
+                                            _vp(smax), 1.0 / ws, _vp(y), None), "mirx_linear_split2h_nchw")
+    torch.cuda.synchronize()
+    err = float((y.double() - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), err
+    # a non-finite device bound poisons the output; a scale without its bound is refused
+    smax.fill_(float("inf"))
+    _lib.check(lib.mirx_linear_split2h_nchw(_vp(x), n_img, tpi, k, _vp(w2), _vp(b), n, None, _vp(sc), xmax, _vp(smax), 1.0 / ws,
+                                            _vp(y), None), "mirx_linear_split2h_nchw")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(y).all())
+    assert lib.mirx_linear_split2h_nchw(_vp(x), n_img, tpi, k, _vp(w2), _vp(b), n, None, _vp(sc), xmax, None, 1.0 / ws, _vp(y),
+                                        None) != 0
+
+
 @pytest.mark.parametrize("n,hw,c", [(3, 144, 512), (2, 577, 192), (1, 5, 4), (4, 2304, 1024)])
 def test_grn_kernels_match_torch(n, hw, c):
     from mirx import _lib
