@@ -6,6 +6,7 @@
 // q * (scale log2 e) * qs, K as k * ks, V as v * vs, the probabilities (in [0, 1]) as p * 1024, and the
 // accumulators are multiplied back by 1 / (qs ks) before the softmax and 1 / (1024 vs) at the end.
 // Layout, key permutation and LDS swizzles are k_attention_s3's; an LDS buffer is 16 KiB instead of 24.
+// k_attention_h2: head_dim 64 (ViT-B / DINOv2); k_attention_h2g<DH>: 32 / 72 / 96.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -229,21 +230,257 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
     }
 }
 
+// ---- any head_dim that is a multiple of 8 (72: the SigLIP-So400m tower) --------------------------------------------
+// k_attention_s3g's generalisation (K rows of KS = ceil(DH / 16) MFMA steps with zero channels beyond DH, 16-byte chunks
+// rotated by key >> 2, NT = ceil(DH / 32) output tiles, staging by item lists) on the two-fp16-term arithmetic above.
+template <int DH>
+__global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restrict__ qkv, int n, int heads, float q_mul,
+                                                          float k_mul, float v_mul, float s_inv, float o_inv,
+                                                          float *__restrict__ out) {
+    constexpr int KS = (DH + 15) / 16, KCH = 2 * KS, KROW = KCH * 16;      // K row: KCH chunks of 16 B
+    constexpr int NT = (DH + 31) / 32;
+    constexpr int KPL = KT * KROW, VPL = DH * 64, GBUF = 2 * (KPL + VPL);
+    extern __shared__ __attribute__((aligned(16))) char smg[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, nq = lane & 31;
+    const int head = blockIdx.y;
+    const int64_t img = blockIdx.z;
+    const int64_t tok = 3 * (int64_t)heads * DH;
+    const float *base = qkv + img * n * tok + head * DH;
+    const int q_idx = blockIdx.x * 128 + wave * 32 + nq;
+    const int q_ld = q_idx < n ? q_idx : n - 1;
+
+    bf16x8 qh[KS], ql[KS];
+    {
+        const float *qp = base + q_ld * tok;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = 16 * ks + 8 * half;                             // DH % 8 == 0: a chunk is all in or all out
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (c0 < DH) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(qp + c0), b = *reinterpret_cast<const f32x4 *>(qp + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = a[j] * q_mul; v[4 + j] = b[j] * q_mul; }
+            }
+            split8(v, qh[ks], ql[ks]);
+        }
+    }
+
+    // ---- staging item lists ----------------------------------------------------------------------------------------
+    constexpr int NKI = KT * KCH, IPK = (NKI + 255) / 256;                // K items: (key, chunk of 8 channels)
+    constexpr int NVI = (KT / 2) * (DH / 4), IPV = (NVI + 255) / 256;     // V items: (key pair, 4 channels)
+    f32x4 rk[IPK][2], rv[IPV][2];
+    auto k_item = [&](int i, int &key, int &c, bool &live) {
+        int it = threadIdx.x + 256 * i;
+        live = it < NKI;
+        if (!live) it = NKI - 1;
+        key = it / KCH;
+        c = it % KCH;
+    };
+    auto v_item = [&](int i, int &m, int &vc, bool &live) {
+        int it = threadIdx.x + 256 * i;
+        live = it < NVI;
+        if (!live) it = NVI - 1;
+        m = it / (DH / 4);
+        vc = it % (DH / 4);
+    };
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < IPK; ++i) {
+            int key, c; bool live;
+            k_item(i, key, c, live);
+            int g = kt * KT + key;
+            if (g >= n) g = n - 1;
+            const int cc = 8 * c < DH ? 8 * c : DH - 8;                    // pad chunk: read something valid, store zeros
+            const float *kp = base + g * tok + heads * DH + cc;
+            rk[i][0] = *reinterpret_cast<const f32x4 *>(kp);
+            rk[i][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < IPV; ++i) {
+            int m, vc; bool live;
+            v_item(i, m, vc, live);
+            int k0 = kt * KT + 2 * m, k1 = k0 + 1;
+            if (k0 >= n) k0 = n - 1;
+            if (k1 >= n) k1 = n - 1;
+            rv[i][0] = *reinterpret_cast<const f32x4 *>(base + k0 * tok + 2 * heads * DH + 4 * vc);
+            rv[i][1] = *reinterpret_cast<const f32x4 *>(base + k1 * tok + 2 * heads * DH + 4 * vc);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char *sb = smg + buf * GBUF;
+#pragma unroll
+        for (int i = 0; i < IPK; ++i) {
+            int key, c; bool live;
+            k_item(i, key, c, live);
+            const float km = 8 * c < DH ? k_mul : 0.f;                     // pad chunk: zeros
+            u32x4 ph, pl;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned th, tl;
+                split2(rk[i][p >> 1][2 * (p & 1)] * km, rk[i][p >> 1][2 * (p & 1) + 1] * km, th, tl);
+                ph[p] = th; pl[p] = tl;
+            }
+            if (live) {
+                const int pos = (c + (key >> 2)) % KCH;
+                char *d = sb + key * KROW + pos * 16;
+                *reinterpret_cast<u32x4 *>(d) = ph;
+                *reinterpret_cast<u32x4 *>(d + KPL) = pl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IPV; ++i) {
+            int m, vc; bool live;
+            v_item(i, m, vc, live);
+            const int vkey = 2 * m;
+            const int vpos = 16 * (vkey >> 4) + 8 * ((vkey >> 2) & 1) + (vkey & 3) + 4 * ((vkey >> 3) & 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned th, tl;
+                split2(rv[i][0][j] * v_mul, rv[i][1][j] * v_mul, th, tl);
+                const int d = 4 * vc + j;
+                char *dst = sb + 2 * KPL + d * 64 + (((vpos >> 3) ^ ((d >> 2) & 3)) << 4) + (vpos & 7) * 2;
+                if (live) {
+                    *reinterpret_cast<unsigned *>(dst) = th;
+                    *reinterpret_cast<unsigned *>(dst + VPL) = tl;
+                }
+            }
+        }
+    };
+
+    int fk[KS], fv[NT][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int pos = (2 * ks + half + (nq >> 2)) % KCH;
+        fk[ks] = nq * KROW + pos * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int d = 32 * t + nq < DH ? 32 * t + nq : DH - 1;
+            fv[t][s] = 2 * KPL + d * 64 + (((2 * s + half) ^ ((d >> 2) & 3)) << 4);
+        }
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = (n + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();
+        load_tile(kt + 1 < ntiles ? kt + 1 : kt);
+        __builtin_amdgcn_sched_barrier(0);
+        const char *sb = smg + cur * GBUF;
+
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fk[ks]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + KPL);
+            MIRX_MFMA3(sacc, ah, al, qh[ks], ql[ks])
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= s_inv;      // exact: a power of two
+
+        const int key0 = kt * KT + 4 * half;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + 8 * (r >> 2) + (r & 3);
+            if (key >= n) sacc[r] = -INFINITY;
+            mt = fmaxf(mt, sacc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = exp2f(sacc[r] - m_new);
+            psum += sacc[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = sacc[8 * s + j] * 1024.f;
+            bf16x8 bh, bl;
+            split8(pv, bh, bl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s] + VPL);
+                MIRX_MFMA3(o[t], ah, al, bh, bl)
+            }
+        }
+        store_tile(cur ^ 1);
+    }
+
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q_idx < n) {
+        const float inv = o_inv / l_run;
+        float *op = out + ((img * n + q_idx) * heads + head) * DH + 4 * half;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (32 * t + 8 * g + 4 * half >= DH) continue;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
+                *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
+template <int DH>
+hipError_t launch_h2g(const float *qkv, int64_t batch, int n, int heads, float q_mul, float k_mul, float v_mul, float s_inv,
+                      float o_inv, float *out, hipStream_t st) {
+    constexpr int KS = (DH + 15) / 16;
+    const size_t lds = (size_t)2 * 2 * (KT * KS * 32 + DH * 64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_h2g<DH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(k_attention_h2g<DH>, grid, dim3(256), lds, st, qkv, n, heads, q_mul, k_mul, v_mul, s_inv, o_inv, out);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale,
                                float qk_bound, float v_bound, float *out, hipStream_t st) {
     if (batch <= 0 || n <= 0) return hipSuccess;
-    if (head_dim != DH || heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
+    if (head_dim != DH && head_dim != 72 && head_dim != 96 && head_dim != 32) return hipErrorInvalidValue;
     if (!(qk_bound > 0.f) || !(v_bound > 0.f) || !(scale > 0.f)) return hipErrorInvalidValue;
     const float sl = scale * 1.4426950408889634f;
     // powers of two that bring each operand's bound to at most 2^14 (fp16 max 65504)
     const float qs = exp2f(floorf(log2f(16384.0f / (qk_bound * sl))));
     const float ks = exp2f(floorf(log2f(16384.0f / qk_bound)));
     const float vs = exp2f(floorf(log2f(16384.0f / v_bound)));
+    const float s_inv = 1.0f / (qs * ks), o_inv = 1.0f / (1024.0f * vs);
+    if (head_dim == 72) return launch_h2g<72>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
+    if (head_dim == 96) return launch_h2g<96>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
+    if (head_dim == 32) return launch_h2g<32>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
     const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
-    hipLaunchKernelGGL(k_attention_h2, grid, dim3(256), 0, st, qkv, n, heads, sl * qs, ks, vs, 1.0f / (qs * ks),
-                       1.0f / (1024.0f * vs), out);
+    hipLaunchKernelGGL(k_attention_h2, grid, dim3(256), 0, st, qkv, n, heads, sl * qs, ks, vs, s_inv, o_inv, out);
     return hipGetLastError();
 }
 

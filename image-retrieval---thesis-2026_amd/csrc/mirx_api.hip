@@ -987,7 +987,8 @@ int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens,
 int mirx_attention_qkv_f32_split2h(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
                                    float qk_bound, float v_bound, float *out, void *stream) {
     MIRX_CHECK(batch >= 0 && n_tokens >= 0 && heads >= 1, "attention_split2h: bad sizes");
-    MIRX_CHECK(head_dim == 64, "attention_split2h: head_dim must be 64");
+    MIRX_CHECK(head_dim == 64 || head_dim == 72 || head_dim == 96 || head_dim == 32,
+               "attention_split2h: head_dim must be 32, 64, 72 or 96");
     MIRX_CHECK(batch <= 65535 && heads <= 65535, "attention_split2h: batch and heads must be <= 65535");
     MIRX_CHECK(batch == 0 || n_tokens == 0 || (qkv && out), "attention_split2h: null buffer");
     MIRX_CHECK(qk_bound > 0.f && v_bound > 0.f && scale > 0.f, "attention_split2h: bounds and scale must be positive");

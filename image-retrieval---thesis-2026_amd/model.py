@@ -488,6 +488,7 @@ def _linear_w3(mod):
 
 
 SPLIT2H_LINEAR = True    # Linears fed by a LayerNorm: two fp16 terms per operand (3 MFMAs per product) instead of three bf16
+SPLIT2H_ATTENTION = True   # flash attention on two fp16 terms where q / k / v have provable bounds (else three bf16 terms)
 
 
 def _linear_h2_weights(mod):
@@ -1209,7 +1210,7 @@ class _VitBlock(nn.Module):
                 lib = _lib.load()
                 bqk = _linear_out_bound(self.norm1, at.qkv, slice(0, 2 * c))
                 bv = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
-                if SPLIT2H_LINEAR and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+                if SPLIT2H_ATTENTION and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
                     # q, k, v are outputs of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
                     _lib.check(lib.mirx_attention_qkv_f32_split2h(_ptr(qkv), b, n, at.num_heads, 64, 0.125, bqk, bv, _ptr(a),
                                                                   _stream(x.device)), "mirx_attention_qkv_f32_split2h")

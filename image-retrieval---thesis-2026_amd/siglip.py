@@ -10,7 +10,8 @@ MedSigLIP / SigLIP checkpoints load unchanged, and whose CUDA fp32 inference pat
   patch embedding  = mirx_patchify_nchw + MFMA Linear (three bf16 terms: the pixel range is unknown)
   LayerNorm        = mirx_layernorm
   q / k / v        = ONE packed MFMA Linear (two fp16 terms: its input is a LayerNorm output, bounded)
-  attention        = vision: flash attention on the matrix pipe at head_dim 72 (mirx_attention_qkv_f32_split3);
+  attention        = vision: flash attention on the matrix pipe at head_dim 72 (mirx_attention_qkv_f32_split2h: two fp16
+                     terms behind the provable q / k / v bounds; _split3 when a bound is not finite);
                      text (64 tokens, key-padding mask) and the pooling head (1 probe query): mirx_attention_small
   out_proj / fc2   = MFMA Linear with the residual added in the epilogue;  fc1 = MFMA Linear + tanh-GELU epilogue
 Other inputs (CPU tensors, autograd, output_attentions=True for the reference's rollout explainer, model.py:546-551) take
@@ -132,7 +133,14 @@ class _EncoderLayer(nn.Module):
         ctx = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             st = _m._stream(x.device)
-            if key_mask is None and n >= 32 and sa.head_dim in (32, 64, 72, 96) and b <= 65535:
+            bqk = max(_m._linear_out_bound(self.layer_norm1, sa.q_proj), _m._linear_out_bound(self.layer_norm1, sa.k_proj))
+            bv = _m._linear_out_bound(self.layer_norm1, sa.v_proj)
+            flash = key_mask is None and n >= 32 and sa.head_dim in (32, 64, 72, 96) and b <= 65535
+            if flash and _m.SPLIT2H_ATTENTION and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+                # q, k, v come out of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
+                _lib.check(lib.mirx_attention_qkv_f32_split2h(_m._ptr(qkv), b, n, sa.num_heads, sa.head_dim, float(sa.scale),
+                                                              bqk, bv, _m._ptr(ctx), st), "mirx_attention_qkv_f32_split2h")
+            elif flash:
                 _lib.check(lib.mirx_attention_qkv_f32_split3(_m._ptr(qkv), b, n, sa.num_heads, sa.head_dim, float(sa.scale),
                                                              _m._ptr(ctx), st), "mirx_attention_qkv_f32_split3")
             else:
@@ -143,7 +151,6 @@ class _EncoderLayer(nn.Module):
                                                     _m._ptr(km) if km is not None else None, b, sa.num_heads, sa.head_dim,
                                                     n, n, float(sa.scale), _m._ptr(ctx), st), "mirx_attention_small")
         # the context is a softmax-weighted average of V rows: bounded like the V rows of the packed projection
-        bv = _m._linear_out_bound(self.layer_norm1, sa.v_proj)
         x = (_m._linear_h2(sa.out_proj, ctx, bv, res=x) if _m._linear_h2_ok(sa.out_proj, ctx, bv)
              else _m._linear_s3(sa.out_proj, ctx, res=x))
         h2 = _m._layernorm(self.layer_norm2, x)

@@ -110,20 +110,20 @@ def test_vit_block_uses_the_kernel_and_matches_sdpa():
 
 
 @pytest.mark.parametrize("b,n,heads", [(1, 1, 1), (2, 5, 3), (1, 33, 1), (3, 127, 2), (2, 257, 12), (1, 1370, 12)])
-@pytest.mark.parametrize("amp", [1.5, 40.0])
-def test_attention_split2h_matches_float64(b, n, heads, amp):
+@pytest.mark.parametrize("amp,dh", [(1.5, 64), (40.0, 64), (1.5, 72), (40.0, 72), (3.0, 32), (3.0, 96)])
+def test_attention_split2h_matches_float64(b, n, heads, amp, dh):
     """mirx_attention_qkv_f32_split2h: two fp16 terms per operand with caller-supplied bounds (here: the actual maxima,
     and values up to a few hundred) -- the tolerance of the other two kernels."""
     from mirx import _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(100 * n + heads)
-    qkv = torch.randn((b, n, 3, heads, 64), generator=g, device=dev) * 1.5
+    qkv = torch.randn((b, n, 3, heads, dh), generator=g, device=dev) * 1.5
     qkv[:, :, 2] *= amp                                               # large values: the scales must absorb them
-    out = torch.full((b, n, heads * 64), float("nan"), device=dev)
+    out = torch.full((b, n, heads * dh), float("nan"), device=dev)
     bqk = float(qkv[:, :, :2].abs().max())
     bv = float(qkv[:, :, 2].abs().max())
-    _lib.check(lib.mirx_attention_qkv_f32_split2h(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, 64, 0.125, bqk, bv,
+    _lib.check(lib.mirx_attention_qkv_f32_split2h(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, dh, dh ** -0.5, bqk, bv,
                                                   ctypes.c_void_p(out.data_ptr()), None), "mirx_attention_qkv_f32_split2h")
     torch.cuda.synchronize()
     ref = _ref(qkv)

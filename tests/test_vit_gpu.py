@@ -47,8 +47,9 @@ def test_medsiglip_tiny_on_gpu():
 
 
 def test_medsiglip_head_dim_72_uses_fused_tower_path():
-    """SigLIP-So400m geometry in small: head_dim 72 -> packed-qkv split-3 Linear + mirx_attention_qkv_f32_split3, MLP width
-    not a multiple of 128 (padded output tile).  CPU (transformers' own modules) vs the routed GPU path."""
+    """SigLIP-So400m geometry in small: head_dim 72 -> packed-qkv Linear + the flash-attention kernel on two fp16 terms
+    (mirx_attention_qkv_f32_split2h, q / k / v bounded through the LayerNorm), MLP width not a multiple of 128 (padded output
+    tile).  CPU (the module graph) vs the routed GPU path."""
     import mirx.model as mm
     torch.manual_seed(1)
     cfg = dict(hidden_size=144, intermediate_size=208, num_hidden_layers=2, num_attention_heads=2, image_size=84,
@@ -60,17 +61,17 @@ def test_medsiglip_head_dim_72_uses_fused_tower_path():
         m = m.cuda()
         calls = []
         lib = mm._lib.load()
-        orig = lib.mirx_attention_qkv_f32_split3
+        orig = lib.mirx_attention_qkv_f32_split2h
 
         class _Spy:
             def __call__(self, *a):
                 calls.append(a[4])
                 return orig(*a)
         try:
-            lib.mirx_attention_qkv_f32_split3 = _Spy()
+            lib.mirx_attention_qkv_f32_split2h = _Spy()
             y = m(x.cuda()).cpu()
         finally:
-            lib.mirx_attention_qkv_f32_split3 = orig
+            lib.mirx_attention_qkv_f32_split2h = orig
     assert calls == [72, 72]                                       # one launch per encoder layer, head_dim 72
     assert float((y - ref).abs().max()) <= 1e-5
     assert m.verify_attention_output("cuda")                       # attention maps still come from the module path

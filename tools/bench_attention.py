@@ -1,4 +1,4 @@
-"""Times the two attention kernels (fp32 MFMA / three-term bf16 MFMA) and torch SDPA on a ViT shape."""
+"""Times the attention kernels (fp32 MFMA / three-term bf16 MFMA / two-term fp16 MFMA) and torch SDPA on a ViT shape."""
 import argparse
 import ctypes
 import os
@@ -17,16 +17,18 @@ def main():
     ap.add_argument("--tokens", type=int, default=1370)
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--head-dim", type=int, default=64)
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    qkv = torch.randn(a.batch, a.tokens, 3, a.heads, 64, device=dev)
-    out = torch.empty(a.batch, a.tokens, a.heads * 64, device=dev)
+    qkv = torch.randn(a.batch, a.tokens, 3, a.heads, a.head_dim, device=dev)
+    out = torch.empty(a.batch, a.tokens, a.heads * a.head_dim, device=dev)
     vp = lambda t: ctypes.c_void_p(t.data_ptr())        # noqa: E731
-    flop = 4.0 * a.batch * a.heads * a.tokens * a.tokens * 64
+    flop = 4.0 * a.batch * a.heads * a.tokens * a.tokens * a.head_dim
     q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    for name, fn in (("fp32 MFMA", lambda: _lib.check(lib.mirx_attention_qkv_f32(vp(qkv), a.batch, a.tokens, a.heads, 64, 0.125, vp(out), None), "a")),
-                     ("split-3 bf16 MFMA", lambda: _lib.check(lib.mirx_attention_qkv_f32_split3(vp(qkv), a.batch, a.tokens, a.heads, 64, 0.125, vp(out), None), "a")),
+    for name, fn in (("fp32 MFMA", lambda: _lib.check(lib.mirx_attention_qkv_f32(vp(qkv), a.batch, a.tokens, a.heads, a.head_dim, a.head_dim ** -0.5, vp(out), None), "a")),
+                     ("split-3 bf16 MFMA", lambda: _lib.check(lib.mirx_attention_qkv_f32_split3(vp(qkv), a.batch, a.tokens, a.heads, a.head_dim, a.head_dim ** -0.5, vp(out), None), "a")),
+                     ("split-2 fp16 MFMA", lambda: _lib.check(lib.mirx_attention_qkv_f32_split2h(vp(qkv), a.batch, a.tokens, a.heads, a.head_dim, a.head_dim ** -0.5, 6.0, 6.0, vp(out), None), "a")),
                      ("torch SDPA fp32", lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v))):
         for _ in range(3):
             fn()

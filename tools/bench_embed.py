@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--no-split3-linear", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (tail overlap)")
     ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
+    ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--no-fused-transition", action="store_true", help="DenseNet: separate bn+relu+avgpool pass before the transition conv")
     ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (terms | direct2h | wino)")
     a = ap.parse_args()
@@ -33,6 +34,8 @@ def main():
     import mirx.model as mm
     if a.no_split2h:
         mm.SPLIT2H_DENSENET = False
+    if a.no_split2h_attention:
+        mm.SPLIT2H_ATTENTION = False
     if a.no_fused_transition:
         mm.FUSED_TRANSITION_POOL = False
     if a.conv3x3:
