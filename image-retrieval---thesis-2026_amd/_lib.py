@@ -66,7 +66,7 @@ SYMBOLS = {
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv1x1_bn_relu_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64,
-                                            _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+                                            _vp, ctypes.c_float, ctypes.c_float, _vp, _i64, _i64, _vp]),
     "mirx_stem_conv7_bn_relu_pool_split3_into": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp]),
     "mirx_conv3x3_winograd_nchw_ranged": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp]),
     "mirx_conv3x3_direct_split2h_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
@@ -76,8 +76,8 @@ SYMBOLS = {
     "mirx_range_absmax": (_int, [_vp, _i64, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool_split2h_into": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split2h_terms": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, ctypes.c_float,
-                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
-    "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
+                                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i64, _vp]),
+    "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "mirx_transition_bn_relu_pool_conv1x1_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp,
                                                            ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
@@ -89,7 +89,7 @@ SYMBOLS = {
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_bn_relu_nchw": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp]),
-    "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv1x1_bn_relu": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_dwconv7x7_nchw_to_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool_split3": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
                                                        float *__restrict__ y, int64_t ybs,
                                                        const float *__restrict__ in_amax, float in_ks, float in_kb,
                                                        unsigned *__restrict__ out_amax, float y_ks, float y_kb,
-                                                       float *__restrict__ y_inv_out, int pool_w) {
+                                                       float *__restrict__ y_inv_out, int pool_w, int64_t xps,
+                                                       int64_t yps) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ float sBias[CM], sOsc[CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
     const int b_kg = wave >> 1;
     // POOL (transitions): x is the un-pooled map [.., 2 ph, 2 pw]; a staged value is the average of relu(bn(.)) over the 2 x 2
     // input pixels of output pixel (oy, ox) -- the norm + relu + avgpool pass and its pooled tensor disappear
-    const int64_t in_hw = POOL ? 4 * (int64_t)hw : (int64_t)hw;       // channel stride of x
+    const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw; POOL: >= 4 hw)
     int64_t b_off = 0;
     {
         const int64_t pp = p0 + b_px;
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         } else {
 #pragma unroll
 #ifdef MIRX_C1H2_NT_LOADS      // experiment (measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images): `nt` activation loads so that the weights stay L2-resident
-        for (int j = 0; j < 8; ++j) r[j] = __builtin_nontemporal_load(&xsrc[((int64_t)kt * KC + j) * hw]);
+        for (int j = 0; j < 8; ++j) r[j] = __builtin_nontemporal_load(&xsrc[((int64_t)kt * KC + j) * in_hw]);
 #else
-        for (int j = 0; j < 8; ++j) r[j] = xsrc[((int64_t)kt * KC + j) * hw];
+        for (int j = 0; j < 8; ++j) r[j] = xsrc[((int64_t)kt * KC + j) * in_hw];
 #endif
         }
         if (PROLOGUE) {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
                 float v = fmaf(acc[mi][ni][r], sOsc[ch - co0], sBias[ch - co0]);
                 if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
                 vmax = range_max(vmax, v);
-                yo[(int64_t)ch * hw] = v;
+                yo[(int64_t)ch * yps] = v;
             }
     }
     if (out_amax) range_publish(out_amax, vmax, lane);
@@ -349,12 +350,16 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, hipStream_t st) {
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, int64_t xps,
+                             int64_t yps, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM || !oscale) return hipErrorInvalidValue;
     const bool yterms = y_inv_out != nullptr;
     if (yterms && (cout != CM || !relu_out || !scale || pool_w)) return hipErrorInvalidValue;
     if (pool_w && (!scale || relu_out || hw % pool_w)) return hipErrorInvalidValue;
+    if (!xps) xps = pool_w ? 4 * (int64_t)hw : hw;     // compact channel planes
+    if (!yps) yps = hw;
+    if (xps < (pool_w ? 4 * (int64_t)hw : hw) || yps < hw) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)STAGE;
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
@@ -364,7 +369,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
         hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, L>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
-                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, pool_w); \
+                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, pool_w, xps, yps); \
     }
     if (pool_w) {
         MIRX_H2C(true, false, false, true)

@@ -287,7 +287,7 @@ template <int W, int R>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
                                                         const float *__restrict__ oscale, float *__restrict__ out,
                                                         int64_t out_bs, const float *__restrict__ in_inv,
-                                                        unsigned *__restrict__ out_range) {
+                                                        unsigned *__restrict__ out_range, int64_t out_ps) {
     constexpr int PW = W + 2, PR = R + 2;     // padded strip
     constexpr int NPIX = PR * PW;             // padded pixels of a stage
     constexpr int NP = (NPIX + 31) / 32;      // 1-KiB DMA pieces per term plane
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
                 const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
                 const float v = acc[t][r] * osc[r];
                 vmax = range_max(vmax, v);
-                oi[(int64_t)oc * (W * W) + p] = v;
+                oi[(int64_t)oc * out_ps + p] = v;
             }
         }
     }
@@ -469,14 +469,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
 
 template <int W, int R>
 hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
-                      const float *in_inv, float *out_range, hipStream_t st) {
+                      const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
     constexpr int NP = ((R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_conv3x3_d2p<W, R>), dim3((W + R - 1) / R, (unsigned)n), dim3(256), lds, st, yt, w2, oscale, out,
-                       out_bs, in_inv, reinterpret_cast<unsigned *>(out_range));
+                       out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps);
     return hipGetLastError();
 }
 
@@ -493,12 +493,14 @@ hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *o
 }
 
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st) {
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (n > 65535 || !in_inv || !oscale) return hipErrorInvalidValue;
-    if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
-    if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
-    if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, st);
+    if (!out_ps) out_ps = (int64_t)side * side;
+    if (out_ps < (int64_t)side * side) return hipErrorInvalidValue;
+    if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     return hipErrorInvalidValue;
 }
 

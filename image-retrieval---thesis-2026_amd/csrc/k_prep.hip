@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_bn_relu(const float *__restrict__ x, in
 __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restrict__ x, int64_t xbs,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int c, int h,
-                                                          int w, int64_t items, float *__restrict__ y) {
+                                                          int w, int64_t items, float *__restrict__ y, int64_t xps) {
     const int oh = h >> 1, ow = w >> 1, pw = (ow + 1) >> 1;
     const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (it >= items) return;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restric
     const int ch = (int)(t2 % c);
     const int64_t b = t2 / c;
     const float sc = scale[ch], sh = shift[ch];
-    const float *xp = x + b * xbs + ((int64_t)ch * h + 2 * oy) * w + 4 * px;
+    const float *xp = x + b * xbs + (int64_t)ch * xps + (int64_t)(2 * oy) * w + 4 * px;    // xps: channel-plane stride (>= h w)
     float *yp = y + ((b * c + ch) * (int64_t)oh + oy) * ow + 2 * px;
     auto act = [&](float v) { return fmaxf(fmaf(v, sc, sh), 0.0f); };
     if (2 * px + 1 < ow) {
@@ -225,13 +225,15 @@ hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const flo
 
 hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
                                    const float *shift, int64_t n, int c, int h, int w, float *y,
-                                   hipStream_t st) {
+                                   int64_t x_plane_stride, hipStream_t st) {
     if (n <= 0) return hipSuccess;
+    if (!x_plane_stride) x_plane_stride = (int64_t)h * w;
     if ((h & 1) || (w & 1) || (x_batch_stride & 1) || n > 65535 || c > 65535) return hipErrorInvalidValue;
+    if (x_plane_stride < (int64_t)h * w || (x_plane_stride & 3)) return hipErrorInvalidValue;   // rows stay 16-byte aligned
     const int64_t items = n * c * (int64_t)(h / 2) * ((w / 2 + 1) / 2);
     if ((items + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_bn_relu_avgpool2, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, x_batch_stride,
-                       scale, shift, c, h, w, items, y);
+                       scale, shift, c, h, w, items, y, x_plane_stride);
     return hipGetLastError();
 }
 

@@ -721,19 +721,22 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                                  const float *shift1_or_null, const void *w2, const float *oscale,
                                  const float *bias_or_null, int64_t n, int hw, int cout, int relu_out, float *y,
                                  int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
-                                 float *out_range_or_null, void *stream) {
+                                 float *out_range_or_null, int64_t x_plane_stride, int64_t y_plane_stride, void *stream) {
     MIRX_CHECK(n >= 0 && hw >= 1 && cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0,
                "conv1x1_split2h: cin must be a multiple of 16 and cout of 128");
+    if (!x_plane_stride) x_plane_stride = hw;
+    if (!y_plane_stride) y_plane_stride = hw;
+    MIRX_CHECK(x_plane_stride >= hw && y_plane_stride >= hw, "conv1x1_split2h: a plane stride is 0 (= hw) or at least hw");
     MIRX_CHECK((scale1_or_null == nullptr) == (shift1_or_null == nullptr), "conv1x1_split2h: scale and shift go together");
     MIRX_CHECK(n == 0 || (x && w2 && y && oscale), "conv1x1_split2h: null buffer");
-    MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1_split2h: batch stride smaller than the channel prefix");
-    MIRX_CHECK(y_batch_stride >= (int64_t)cout * hw, "conv1x1_split2h: output batch stride smaller than cout * hw");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * x_plane_stride, "conv1x1_split2h: batch stride smaller than the channel prefix");
+    MIRX_CHECK(y_batch_stride >= (int64_t)cout * y_plane_stride, "conv1x1_split2h: output batch stride smaller than cout planes");
     MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && (in_range_or_null || in_kb > 0.f),
                "conv1x1_split2h: in_ks / in_kb are non-negative; without range slots in_kb is the bound itself");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
                                reinterpret_cast<const uint16_t *>(w2), oscale, bias_or_null, n, hw, cout, relu_out, y,
                                y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr, 0,
-                               reinterpret_cast<hipStream_t>(stream)));
+                               x_plane_stride, y_plane_stride, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
@@ -749,31 +752,37 @@ int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch
     MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f, "transition: bounds are non-negative");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale, shift, reinterpret_cast<const uint16_t *>(w2), oscale, nullptr, n,
                                (h / 2) * (w / 2), cout, 0, y, y_batch_stride, in_range, in_ks, in_kb, out_range_or_null, 0.f,
-                               0.f, nullptr, w / 2, reinterpret_cast<hipStream_t>(stream)));
+                               0.f, nullptr, w / 2, 0, 0, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
 int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
                                        const float *shift1, const void *w2, const float *oscale, const float *bias,
                                        int64_t n, int hw, void *y_terms, const float *in_range, float in_ks, float in_kb,
-                                       float y_ks, float y_kb, float *y_inv_out, void *stream) {
+                                       float y_ks, float y_kb, float *y_inv_out, int64_t x_plane_stride, void *stream) {
     MIRX_CHECK(n >= 0 && hw >= 1 && cin >= 16 && cin % 16 == 0, "conv1x1_split2h_terms: cin must be a multiple of 16");
     MIRX_CHECK(n == 0 || (x && w2 && y_terms && oscale && scale1 && shift1 && bias && in_range && y_inv_out),
                "conv1x1_split2h_terms: null buffer");
-    MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1_split2h_terms: batch stride smaller than the channel prefix");
+    if (!x_plane_stride) x_plane_stride = hw;
+    MIRX_CHECK(x_plane_stride >= hw, "conv1x1_split2h_terms: the plane stride is 0 (= hw) or at least hw");
+    MIRX_CHECK(x_batch_stride >= (int64_t)cin * x_plane_stride, "conv1x1_split2h_terms: batch stride smaller than the channel prefix");
     MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && y_ks >= 0.f && y_kb >= 0.f, "conv1x1_split2h_terms: bounds are non-negative");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1, shift1, reinterpret_cast<const uint16_t *>(w2), oscale, bias, n,
                                hw, 128, 1, reinterpret_cast<float *>(y_terms), 0, in_range, in_ks, in_kb, nullptr, y_ks, y_kb,
-                               y_inv_out, 0, reinterpret_cast<hipStream_t>(stream)));
+                               y_inv_out, 0, x_plane_stride, 0, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
-                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null, void *stream) {
+                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                   int64_t out_plane_stride, void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
     MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms: side must be 56, 28 or 14");
     MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
-    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_terms: output batch stride too small");
+    if (!out_plane_stride) out_plane_stride = (int64_t)side * side;
+    MIRX_CHECK(out_plane_stride >= (int64_t)side * side && out_plane_stride % 4 == 0,
+               "conv3x3_terms: the plane stride is 0 (= side^2) or a multiple of 4 that is at least side^2");
+    MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms: output batch stride too small");
     MIRX_CHECK((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0,
                "conv3x3_terms: out must be 16-byte aligned and the batch stride a multiple of 4 floats");
 #ifndef MIRX_CONV3X3_TERMS_MFMA
@@ -781,10 +790,12 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
 #endif
 #if MIRX_CONV3X3_TERMS_MFMA == 16
     MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                side, out, out_batch_stride, y_inv, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                reinterpret_cast<hipStream_t>(stream)));
 #else
     MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                side, out, out_batch_stride, y_inv, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                reinterpret_cast<hipStream_t>(stream)));
 #endif
     return MIRX_OK;
 }
@@ -1047,11 +1058,13 @@ int mirx_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale
 }
 
 int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
-                          int64_t n, int c, int h, int w, float *y, void *stream) {
+                          int64_t n, int c, int h, int w, float *y, int64_t x_plane_stride, void *stream) {
     MIRX_CHECK(x && scale && shift && y && n >= 0 && c >= 1, "bn_relu_avgpool2: bad argument");
     MIRX_CHECK(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && x_batch_stride % 2 == 0,
                "bn_relu_avgpool2: h, w and the batch stride must be even");
-    MIRX_HIP(launch_bn_relu_avgpool2(x, x_batch_stride, scale, shift, n, c, h, w, y,
+    MIRX_CHECK(x_plane_stride == 0 || (x_plane_stride >= (int64_t)h * w && x_plane_stride % 4 == 0),
+               "bn_relu_avgpool2: the plane stride is 0 (= h * w) or a multiple of 4 that is at least h * w");
+    MIRX_HIP(launch_bn_relu_avgpool2(x, x_batch_stride, scale, shift, n, c, h, w, y, x_plane_stride,
                                      reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }

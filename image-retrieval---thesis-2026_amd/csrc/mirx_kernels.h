@@ -22,7 +22,7 @@ hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const flo
                                const float *shift, int64_t n, int c, int hw, float *y, hipStream_t st);
 hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
                                    const float *shift, int64_t n, int c, int h, int w, float *y,
-                                   hipStream_t st);
+                                   int64_t x_plane_stride, hipStream_t st);
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 // k_stem_s3.hip: the same stem on three-term bf16 MFMAs; w3 = pre-split weights [2][11][3][32][16] bf16
@@ -78,7 +78,8 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, hipStream_t st);
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, int64_t xps,
+                             int64_t yps, hipStream_t st);
 
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
@@ -117,10 +118,10 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
 
 // k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st);
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
 // k_conv3x3_d2q.hip: the same on v_mfma_f32_16x16x32_f16 (A/B arm, -DMIRX_CONV3X3_TERMS_MFMA=16; `out` 16-byte aligned)
 hipError_t launch_conv3x3_d2q(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, hipStream_t st);
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,

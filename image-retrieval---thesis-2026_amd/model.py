@@ -180,7 +180,7 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
         return tr.pool(tr.conv(F.relu(F.batch_norm(buf, tr.norm.running_mean, tr.norm.running_var,
                                                    tr.norm.weight, tr.norm.bias, False, 0.0, tr.norm.eps))))
     pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
-    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled),
+    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled), 0,
                                          _stream(buf.device)), "mirx_bn_relu_avgpool2")
     if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
         ev = _timer_start(timer)
@@ -204,37 +204,58 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
     return F.conv2d(pooled, tr.conv.weight)
 
 
-def _dense_block_h2(block, buf, cache, brange, lranges, timer=None):
-    """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, h, h] already holds the first block.cin
-    channels and `brange` (64 range slots) bounds them.  Every layer on the 56 / 28 / 14 maps: conv1x1 (norm1 + relu1
-    prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT into fp16 terms, scaled by a bound it derives
-    from brange before it runs (2^-t goes to the layer's row of `lranges`); conv3x3 stages those terms by DMA, writes 32
-    channels into the buffer and folds their range into brange.  7 x 7 maps: fp32 bottleneck + fp32 Winograd."""
+PLANE_STRIDE_H2 = {}       # map side -> floats between channel planes of that block's buffer (absent: packed, side^2)
+
+
+def _plane_stride(side):
+    """Floats between consecutive channel planes of a dense block's buffer on the two-fp16-term path (terms kernels only).
+    784-byte (14 x 14) and 3136-byte (28 x 28) planes start at every 16-byte offset of a 128-byte line, so a wave's 256-byte
+    load straddles three lines instead of two; in isolation the block-3 conv1x1 layers run at 4.1 instead of 3.5 TB/s on
+    line-aligned planes (stride 224).  In the whole forward the padded layouts measured 1 % SLOWER (42.4 vs 42.8 k img/s,
+    same box, B = 4096), so the default stays packed; the kernels and the ABI take the stride
+    (tools/bench_embed.py --plane-stride 14:224)."""
+    hw = side * side
+    ps = PLANE_STRIDE_H2.get(side, hw)
+    if CONV3X3_KERNEL_H2.get(side, "wino") != "terms":
+        return hw
+    assert ps >= hw and ps % 4 == 0
+    return ps
+
+
+def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None):
+    """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, plane stride] (side x side pixels per plane, see
+    _plane_stride) already holds the first block.cin channels and `brange` (64 range slots) bounds them.  Every layer on
+    the 56 / 28 / 14 maps: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT
+    into fp16 terms, scaled by a bound it derives from brange before it runs (2^-t goes to the layer's row of `lranges`);
+    conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange.  7 x 7 maps:
+    fp32 bottleneck + fp32 Winograd."""
     lib = _lib.load()
-    b, _, h, w = buf.shape
+    b, _, ps = buf.shape
+    h = w = side
     st = _stream(buf.device)
     c = block.cin
     terms = CONV3X3_KERNEL_H2.get(h, "wino") == "terms"
+    assert terms or ps == h * w                                   # only the terms kernels take a plane stride
     y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)      # fp32 map, or the same bytes as terms
     for li, name in enumerate(block.keys()):
         e = cache[name]
-        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
+        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * ps)
         ev = _timer_start(timer)
         if terms:
-            _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
+            _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * ps, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
                                                               _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, _ptr(y),
                                                               _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
-                                                              _ptr(lranges[li]), st), "mirx_conv1x1_bn_relu_split2h_terms")
+                                                              _ptr(lranges[li]), ps, st), "mirx_conv1x1_bn_relu_split2h_terms")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
             _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
-                                                          block.cout * h * w, _ptr(lranges[li]), _ptr(brange), st),
+                                                          block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
                        "mirx_conv3x3_direct_terms_nchw")
             c += GROWTH
             continue
         _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
                                                     _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, y.shape[1], 1,
                                                     _ptr(y), y.shape[1] * h * w, _ptr(brange), e["ks"], e["kb"],
-                                                    _ptr(lranges[li]), st), "mirx_conv1x1_bn_relu_split2h")
+                                                    _ptr(lranges[li]), 0, 0, st), "mirx_conv1x1_bn_relu_split2h")
         _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
         if CONV3X3_KERNEL_H2.get(h, "wino") == "direct2h":
             _lib.check(lib.mirx_conv3x3_direct_split2h_nchw(_ptr(y), _ptr(e["c3w2"]), _ptr(e["c3osc"]), b, h, dst,
@@ -249,19 +270,22 @@ def _dense_block_h2(block, buf, cache, brange, lranges, timer=None):
 
 # transitions: norm + relu + avgpool inside the 1x1 conv's staging (one launch).  Measured equal within noise (43.0 vs 43.2 k
 # img/s at B = 4096): each of the cout / 128 channel tiles re-reads the un-pooled map, which costs what the saved pass cost.
+# (Packed planes only.)
 FUSED_TRANSITION_POOL = False
 
 
-def _transition_h2(buf, cache, brange, next_buf, next_range, timer=None):
+def _transition_h2(buf, side, cache, brange, next_buf, next_range, timer=None):
     """norm -> relu -> avgpool2 -> conv 1x1 (the pool commutes with the linear conv; two fp16 terms; the pooled values are
     averages of relu(bn(x)), so max|scale| * range + max|shift| bounds them) written into the channel prefix of the next
-    block's buffer, whose range slots receive the output range.  FUSED_TRANSITION_POOL: one launch, the pool runs in the conv's
-    staging; otherwise a bn + relu + avgpool pass feeds the plain 1x1 conv."""
+    block's buffer [B, C', its plane stride], whose range slots receive the output range.  FUSED_TRANSITION_POOL: one launch,
+    the pool runs in the conv's staging; otherwise a bn + relu + avgpool pass feeds the plain 1x1 conv."""
     lib = _lib.load()
-    b, c, h, w = buf.shape
+    b, c, ps = buf.shape
+    h = w = side
     st = _stream(buf.device)
     hw2 = (h // 2) * (w // 2)
-    if FUSED_TRANSITION_POOL:
+    nps = next_buf.shape[2]
+    if FUSED_TRANSITION_POOL and ps == h * w and nps == hw2:
         ev = _timer_start(timer)
         _lib.check(lib.mirx_transition_bn_relu_pool_conv1x1_split2h(
             _ptr(buf), c * h * w, c, _ptr(cache["sc"]), _ptr(cache["sh"]), _ptr(cache["w2"]), _ptr(cache["osc"]), b, h, w,
@@ -270,12 +294,12 @@ def _transition_h2(buf, cache, brange, next_buf, next_range, timer=None):
         _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2))
         return next_buf
     pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
-    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled),
+    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * ps, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled), ps,
                                          st), "mirx_bn_relu_avgpool2")
     ev = _timer_start(timer)
     _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(pooled), c * hw2, c, None, None, _ptr(cache["w2"]), _ptr(cache["osc"]),
-                                                None, b, hw2, c // 2, 0, _ptr(next_buf), next_buf.shape[1] * hw2,
-                                                _ptr(brange), cache["ks"], cache["kb"], _ptr(next_range), st),
+                                                None, b, hw2, c // 2, 0, _ptr(next_buf), next_buf.shape[1] * nps,
+                                                _ptr(brange), cache["ks"], cache["kb"], _ptr(next_range), 0, nps, st),
                "mirx_conv1x1_bn_relu_split2h")
     _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2))
     return next_buf
@@ -869,7 +893,7 @@ class DenseNet121(nn.Module):
         nlayers = sum(len(m) for _, m in blocks)
         ranges = torch.zeros((len(blocks) + nlayers + 1, 64), dtype=torch.float32, device=dev)  # one fill per forward
         side = 56
-        buf = torch.empty((b, blocks[0][1].cout, side, side), dtype=torch.float32, device=dev)
+        buf = torch.empty((b, blocks[0][1].cout, _plane_stride(side)), dtype=torch.float32, device=dev)    # [B, C, plane]
         sc, sh = cache["norm0"]
         xr = ranges[len(blocks) + nlayers]                           # the range of the input images: one pass over them
         _lib.check(lib.mirx_range_absmax(_ptr(x), x.numel(), _ptr(xr), st), "mirx_range_absmax")
@@ -879,13 +903,14 @@ class DenseNet121(nn.Module):
                                                                  _ptr(ranges[0]), st), "mirx_stem_split2h_into")
         row = len(blocks)
         for k, (name, blk) in enumerate(blocks):
-            _dense_block_h2(blk, buf, h2[name], ranges[k], ranges[row:row + len(blk)], self.conv1x1_timer)
+            _dense_block_h2(blk, buf, side, ranges[k], h2[name], ranges[row:row + len(blk)], self.conv1x1_timer)
             row += len(blk)
             if k + 1 < len(blocks):
+                nxt = torch.empty((b, blocks[k + 1][1].cout, _plane_stride(side // 2)), dtype=torch.float32, device=dev)
+                _transition_h2(buf, side, h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
                 side //= 2
-                nxt = torch.empty((b, blocks[k + 1][1].cout, side, side), dtype=torch.float32, device=dev)
-                _transition_h2(buf, h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
                 buf = nxt
+        buf = buf.view(b, buf.shape[1], side, side)                 # the 7 x 7 planes are packed
         self.__dict__["_mirx_last_ranges"] = ranges            # kept for diagnostics (tools/h2_state_probe.py)
         return buf
 

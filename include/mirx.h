@@ -200,6 +200,9 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
  * wrong finite value).  w2 = device fp16 [cout / 128][cin / 16][2][128][16]: the two terms of W[co, k] * ws[co], ws a
  * power of two per output channel (mirx.model._split2h_weights); oscale = device fp32 [cout] = 1 / ws.
  * `out_range_or_null`: range slots that receive the largest |y| written (device fp32 [64], atomic max).
+ * x_plane_stride / y_plane_stride: floats between consecutive channel planes of x / y (0 = hw, packed planes).  A dense
+ * block's buffer may pad its planes to a multiple of 32 floats: with 784-byte planes (14 x 14) a wave's 256-byte load
+ * straddles three 128-byte lines instead of two, which costs 15 % of the layer (measured: 3.5 vs 4.1 TB/s).
  * Otherwise the contract of mirx_conv1x1_bn_relu_split3 (reference: the conv1 / transition conv calls inside
  * torchvision densenet121, model.py:53-60).
  */
@@ -207,7 +210,7 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                                  const float *shift1_or_null, const void *w2, const float *oscale,
                                  const float *bias_or_null, int64_t n, int hw, int cout, int relu_out, float *y,
                                  int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
-                                 float *out_range_or_null, void *stream);
+                                 float *out_range_or_null, int64_t x_plane_stride, int64_t y_plane_stride, void *stream);
 
 /* DenseNet transition (norm -> relu -> conv 1x1 -> avgpool 2x2, torchvision _Transition) in ONE launch: the average pool is
  * moved in front of the (linear) convolution and into its staging -- a staged value is the mean of relu(bn(x)) over the
@@ -230,13 +233,16 @@ int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch
  *       [2^14, 2^15); y_inv_out[0] receives 2^-t.
  *   mirx_conv3x3_direct_terms_nchw: mirx_conv3x3_direct_split2h_nchw reading such y_terms and y_inv; the padding ring of the
  *       staged strip comes from out-of-range buffer loads (zero), w2 in the permuted channel order.
+ *   x_plane_stride / out_plane_stride: floats between consecutive channel planes of the dense block's buffer (0 = packed,
+ *       hw resp. side^2; see mirx_conv1x1_bn_relu_split2h).
  */
 int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
                                        const float *shift1, const void *w2, const float *oscale, const float *bias,
                                        int64_t n, int hw, void *y_terms, const float *in_range, float in_ks, float in_kb,
-                                       float y_ks, float y_kb, float *y_inv_out, void *stream);
+                                       float y_ks, float y_kb, float *y_inv_out, int64_t x_plane_stride, void *stream);
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
-                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null, void *stream);
+                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                   int64_t out_plane_stride, void *stream);
 
 /*
  * Range-publishing forms of the DenseNet producers (the two-fp16-term kernels need the range of what they read; see
@@ -472,7 +478,8 @@ int mirx_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale
  * the average pool, so the caller runs it on the pooled map (4x fewer pixels).
  */
 int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
-                          const float *shift, int64_t n, int c, int h, int w, float *y, void *stream);
+                          const float *shift, int64_t n, int c, int h, int w, float *y, int64_t x_plane_stride,
+                          void *stream);    /* x_plane_stride: floats between channel planes of x (0 = h * w; else % 4 == 0) */
 
 /*
  * DenseNet stem: conv 7x7 stride 2 pad 3 (3 -> 64 channels) + folded BatchNorm + ReLU +

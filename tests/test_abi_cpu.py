@@ -25,6 +25,32 @@ def test_header_symbols_all_bound_and_exported():
         assert hasattr(lib, n)
 
 
+def test_ctypes_signatures_match_the_header():
+    """Every entry of the ctypes table has as many argtypes as the C declaration has parameters, and integer / pointer /
+    float kinds agree position by position (a missing argtype would still 'work' on x86-64 until a 64-bit value arrives)."""
+    import ctypes
+    import mirx._lib as L
+    text = open(os.path.join(ROOT, "include", "mirx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, (_res, args) in L.SYMBOLS.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, text, re.S)
+        assert m, name
+        params = [p.strip() for p in m.group(1).split(",")] if m.group(1).strip() not in ("", "void") else []
+        assert len(params) == len(args), (name, len(params), len(args))
+        for p, a in zip(params, args):
+            if "*" in p:
+                assert a is ctypes.c_void_p or isinstance(a, type(ctypes.POINTER(ctypes.c_int))) and a is not ctypes.c_float, (name, p)
+                assert a not in (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double), (name, p)
+            elif p.startswith("int64_t"):
+                assert a is ctypes.c_int64, (name, p)
+            elif p.startswith("int "):
+                assert a is ctypes.c_int, (name, p)
+            elif p.startswith("float "):
+                assert a is ctypes.c_float, (name, p)
+            elif p.startswith("double "):
+                assert a is ctypes.c_double, (name, p)
+
+
 def test_bad_arguments_report_errors_without_gpu():
     import ctypes
     import mirx._lib as L

@@ -118,7 +118,7 @@ def test_fused_elementwise_kernels():
             yp = torch.empty((b, c, h // 2, w // 2), device="cuda")
             assert lib.mirx_bn_relu_avgpool2(ctypes.c_void_p(bg.data_ptr()), ctot * h * w,
                                              ctypes.c_void_p(scg.data_ptr()), ctypes.c_void_p(shg.data_ptr()),
-                                             b, c, h, w, ctypes.c_void_p(yp.data_ptr()), None) == 0
+                                             b, c, h, w, ctypes.c_void_p(yp.data_ptr()), 0, None) == 0
             torch.cuda.synchronize()
             torch.testing.assert_close(yp.cpu(), want_p, atol=1e-6, rtol=1e-6)
 
@@ -340,7 +340,7 @@ def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
     _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
                                                 vp(sh) if prologue else None, vp(w2), vp(osc), vp(bias), n, hw, cout,
                                                 1 if relu else 0, vp(y), (cout + 8) * hw, vp(slots_in), ks, kb,
-                                                vp(slots_out), None), "split2h")
+                                                vp(slots_out), 0, 0, None), "split2h")
     torch.cuda.synchronize()
     xin = buf[:, :cin].double()
     if prologue:
@@ -356,10 +356,57 @@ def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
     slots_in[0] = float("inf")
     _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc) if prologue else None,
                                                 vp(sh) if prologue else None, vp(w2), vp(osc), vp(bias), n, hw, cout,
-                                                1 if relu else 0, vp(y), (cout + 8) * hw, vp(slots_in), ks, kb, None, None),
+                                                1 if relu else 0, vp(y), (cout + 8) * hw, vp(slots_in), ks, kb, None, 0, 0, None),
                "split2h")
     torch.cuda.synchronize()
     assert bool(torch.isnan(y).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,side,n,pad_in,pad_out", [(256, 28, 3, 16, 28), (512, 14, 2, 28, 0), (256, 56, 1, 0, 16)])
+def test_transition_kernels_with_padded_planes(c, side, n, pad_in, pad_out):
+    """The two launches of a transition on buffers whose channel planes are padded (mirx.model._plane_stride):
+    mirx_bn_relu_avgpool2 reads planes `x_plane_stride` apart, mirx_conv1x1_bn_relu_split2h writes planes `y_plane_stride`
+    apart; the gaps hold NaN before and after (never read, never written)."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(c + side)
+    hw, hw2 = side * side, (side // 2) ** 2
+    ps, ps2 = hw + pad_in, hw2 + pad_out
+    cout = c // 2
+    xs = torch.full((n, c, ps), float("nan"), device=dev)
+    x = xs[:, :, :hw].unflatten(2, (side, side))
+    x.copy_(torch.randn(n, c, side, side, generator=g, device=dev))
+    sc = torch.rand(c, generator=g, device=dev) + 0.5
+    sh = torch.randn(c, generator=g, device=dev) * 0.3
+    wt = torch.randn(cout, c, generator=g, device=dev) / c ** 0.5
+    w2, osc = _split2h_weights(wt)
+    pooled = torch.empty((n, c, side // 2, side // 2), device=dev)
+    ys = torch.full((n, cout + 32, ps2), float("nan"), device=dev)
+    rng_in = torch.zeros(64, device=dev)
+    rng_in[9] = float(x.abs().max())
+    rng_out = torch.zeros(64, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    _lib.check(lib.mirx_bn_relu_avgpool2(vp(xs), c * ps, vp(sc), vp(sh), n, c, side, side, vp(pooled), ps if pad_in else 0, None),
+               "avgpool")
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(pooled), c * hw2, c, None, None, vp(w2), vp(osc), None, n, hw2, cout, 0, vp(ys),
+                                                (cout + 32) * ps2, vp(rng_in), float(sc.abs().max()), float(sh.abs().max()),
+                                                vp(rng_out), 0, ps2 if pad_out else 0, None), "conv")
+    torch.cuda.synchronize()
+    act = torch.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    want_p = torch.nn.functional.avg_pool2d(act, 2)
+    assert float((pooled.double() - want_p).abs().max()) < 1e-6
+    want = torch.einsum("oc,bchw->bohw", wt.double(), want_p).flatten(2)
+    got = ys[:, :cout, :hw2].double()
+    assert float((got - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
+    assert bool(torch.isnan(ys[:, cout:]).all()) and bool(torch.isnan(ys[:, :, hw2:]).all())
+    assert bool(torch.isnan(xs[:, :, hw:]).all())
+    assert float(rng_out.max()) == float(ys[:, :cout, :hw2].abs().max())
+    # a plane stride below the plane is refused
+    assert lib.mirx_bn_relu_avgpool2(vp(xs), c * ps, vp(sc), vp(sh), n, c, side, side, vp(pooled), hw - 4, None) != 0
 
 
 @pytest.mark.gpu
@@ -525,12 +572,15 @@ def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("side,batch,cin,mag", [(56, 2, 64, 1.0), (28, 3, 256, 25.0), (14, 5, 512, 1e-2), (14, 1, 1008, 1.0)])
-def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag):
+@pytest.mark.parametrize("side,batch,cin,mag,pad", [(56, 2, 64, 1.0, 0), (28, 3, 256, 25.0, 0), (14, 5, 512, 1e-2, 0),
+                                                    (14, 1, 1008, 1.0, 0), (14, 3, 512, 1.0, 28), (28, 2, 128, 3.0, 16),
+                                                    (56, 1, 96, 1.0, 32)])
+def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad):
     """conv1x1 -> pre-split fp16-term bottleneck -> conv3x3 (mirx_conv1x1_bn_relu_split2h_terms +
     mirx_conv3x3_direct_terms_nchw) against a float64 dense layer relu(bn2(conv1(relu(bn1(x))))) -> conv2: 3e-6 of the
     largest output at any input magnitude; the halo ring of the DMA-staged strips is zero (out-of-range buffer loads);
-    neighbours of the written channel slice untouched; the output range published exactly."""
+    neighbours of the written channel slice untouched; the output range published exactly.  pad > 0: the block buffer's
+    channel planes are `pad` floats apart beyond side^2 (plane stride); the gaps hold NaN, are never read and never written."""
     import ctypes
     from mirx import _lib
     from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
@@ -539,7 +589,10 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag):
     g = torch.Generator(device=dev).manual_seed(side + cin)
     ctot = cin + 64
     hw = side * side
-    buf = torch.randn(batch, ctot, side, side, generator=g, device=dev) * mag
+    ps = hw + pad
+    store = torch.full((batch, ctot, ps), float("nan"), device=dev)
+    buf = store[:, :, :hw].unflatten(2, (side, side))                   # a view: [batch, ctot, side, side] with plane stride ps
+    buf.copy_(torch.randn(batch, ctot, side, side, generator=g, device=dev) * mag)
     buf[:, cin:] = 7.0 * mag
     sc = torch.rand(cin, generator=g, device=dev) + 0.5
     sh = torch.randn(cin, generator=g, device=dev) * 0.3 * mag
@@ -554,13 +607,13 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag):
     brange[5] = float(buf[:, :cin].abs().max())
     yinv = torch.zeros(64, device=dev)
     vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
-    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(buf), ctot * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), batch, hw,
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(store), ctot * ps, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), batch, hw,
                                                       vp(y), vp(brange), float(sc.abs().max()), float(sh.abs().max()),
-                                                      float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv), None),
-               "terms")
+                                                      float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv),
+                                                      ps if pad else 0, None), "terms")
     rng_before = float(brange.max())
-    _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), batch, side, vp(buf, 4 * cin * hw), ctot * hw,
-                                                  vp(yinv), vp(brange), None), "conv3x3_terms")
+    _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), batch, side, vp(store, 4 * cin * ps), ctot * ps,
+                                                  vp(yinv), vp(brange), ps if pad else 0, None), "conv3x3_terms")
     torch.cuda.synchronize()
     x64 = torch.relu(buf[:, :cin].double().cpu() * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None])
     y64 = torch.relu(torch.einsum("oc,bchw->bohw", w1.double().cpu(), x64) + b1.double().cpu()[None, :, None, None])
@@ -568,4 +621,5 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag):
     got = buf[:, cin:cin + 32].double().cpu()
     assert float((got - want).abs().max()) < 3e-6 * float(want.abs().max())
     assert bool((buf[:, cin + 32:] == 7.0 * mag).all())                  # neighbours untouched
+    assert pad == 0 or bool(torch.isnan(store[:, :, hw:]).all())         # plane gaps untouched (and, being NaN, unread)
     assert float(yinv[0]) > 0 and float(brange.max()) == max(rng_before, float(buf[:, cin:cin + 32].abs().max()))

@@ -22,21 +22,24 @@ def run(lib, kind, buf, ctot, cin, sc, sh, w3, w2, osc, bias, n, hw, y, slots_in
                                                    vp(y), 128 * hw, None), "s3")
     else:
         _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(bias), n, hw,
-                                                    128, 1, vp(y), 128 * hw, vp(slots_in), ks, kb, vp(slots_out), None), "h2")
+                                                    128, 1, vp(y), 128 * hw, vp(slots_in), ks, kb, vp(slots_out), 0, 0, None), "h2")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--hw", type=int, nargs="*", default=None, help="experiment: block-3 layer set (256..992 channels) at these pixel counts per image")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     blocks = ((56, 64, 6), (28, 128, 12), (14, 256, 24), (7, 512, 16))
+    if a.hw:
+        blocks = tuple((-h, 256, 24) for h in a.hw)
     tot = {"s3": 0.0, "h2": 0.0}
     for side, c0, nl in blocks:
-        hw = side * side
+        hw = side * side if side > 0 else -side
         ctot = c0 + 32 * nl
         buf = torch.randn(a.batch, ctot, hw, generator=g, device=dev)
         y = torch.empty(a.batch, 128, hw, device=dev)

@@ -44,7 +44,7 @@ def main():
             yt = (torch.randn(a.batch, 8, 2, side * side, 16, generator=g, device=dev) * 100).half()
             yinv = torch.full((1,), 2.0 ** -7, device=dev)
             kinds["terms"] = lambda: lib.mirx_conv3x3_direct_terms_nchw(vp(yt), vp(w2), vp(osc), a.batch, side, vp(out), bs,
-                                                                        vp(yinv), vp(rout), None)
+                                                                        vp(yinv), vp(rout), 0, None)
         for name, fn in kinds.items():
             for it in range(a.iters + 2):
                 if it == 2:

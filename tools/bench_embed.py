@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (tail overlap)")
     ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
+    ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
     ap.add_argument("--no-fused-transition", action="store_true", help="DenseNet: separate bn+relu+avgpool pass before the transition conv")
     ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (terms | direct2h | wino)")
     a = ap.parse_args()
@@ -36,6 +37,8 @@ def main():
         mm.SPLIT2H_DENSENET = False
     if a.no_split2h_attention:
         mm.SPLIT2H_ATTENTION = False
+    for kv in filter(None, a.plane_stride.split(",")):
+        mm.PLANE_STRIDE_H2[int(kv.split(":")[0])] = int(kv.split(":")[1])
     if a.no_fused_transition:
         mm.FUSED_TRANSITION_POOL = False
     if a.conv3x3:

@@ -45,7 +45,7 @@ def main():
             yt = (torch.randn(1024, 8, 2, sd * sd, 16, generator=g, device=dev) * 100).half()
             oo = torch.empty(1024, 32, sd, sd, device=dev)
             measure(f"k_conv3x3_d2p<{sd}> (1024 images)", lambda: _lib.check(lib.mirx_conv3x3_direct_terms_nchw(
-                vp(yt), vp(w2), vp(osc), 1024, sd, vp(oo), 32 * sd * sd, vp(yinv), None, None), "c"))
+                vp(yt), vp(w2), vp(osc), 1024, sd, vp(oo), 32 * sd * sd, vp(yinv), None, 0, None), "c"))
         cin, hw = 256, 3136
         xb = torch.randn(1024, cin, hw, generator=g, device=dev)
         w1, o1 = _split2h_weights(torch.randn(128, cin, generator=g, device=dev) / 16)
@@ -55,7 +55,7 @@ def main():
         ytt = torch.empty(1024, 8, 2, hw, 16, dtype=torch.float16, device=dev)
         measure("k_conv1x1_h2 terms 256 -> 128 @56 (1024)", lambda: _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(
             vp(xb), cin * hw, cin, vp(sc), vp(sh), vp(w1), vp(o1), vp(bias), 1024, hw, vp(ytt), vp(rng), 1.0, 0.0, 16.0, 0.0,
-            vp(yinv), None), "c"))
+            vp(yinv), 0, None), "c"))
         return
     # distance GEMM: 8192 queries over 1M x 1024
     g = torch.Generator(device=dev).manual_seed(0)
