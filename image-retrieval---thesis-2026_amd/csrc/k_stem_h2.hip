@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 constexpr int PTH = 8, PTW = 7;              // pooled tile
@@ -64,6 +65,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     const float *xi = x + img * 3 * (int64_t)h * wd;
     float x_scale, x_inv;
     range_scales(range_read(in_range), x_scale, x_inv);
+    // per-channel epilogue constants (accumulator scale, norm0 scale and shift) once per workgroup: the epilogue reads them
+    // from LDS instead of three cached global loads per accumulator register
+    float *s_par = sm + S_ALL;           // [64][4]: oscale * 2^-s, scale, shift
+    if (threadIdx.x < NOB * OCB) {
+        s_par[4 * threadIdx.x] = oscale[threadIdx.x] * x_inv;
+        s_par[4 * threadIdx.x + 1] = scale[threadIdx.x];
+        s_par[4 * threadIdx.x + 2] = shift[threadIdx.x];
+    }
 
     // ---- patch staging: all global loads of a thread are issued before its first LDS store ---------------------
     // element i -> (channel, row, column of a 36-wide row: columns 35 = kx 7 of the last pixel is written as zero);
@@ -80,11 +89,19 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
         if (i < 3 * ITH * ROWW && q < ITW && yy >= 0 && yy < h && xx >= 0 && xx < wd)
             vin[t] = xi[((int64_t)c * h + yy) * wd + xx];
     }
+    // The patch is split into its two fp16 terms HERE, once per input value, and stored as one 32-bit word (hi | lo << 16)
+    // in the slot the fp32 value used to take: a B fragment is then 8 word reads and 8 v_perm_b32 -- a value is part of ~11
+    // fragments, and splitting it in every one of them (~30 VALU instructions per fragment) bounded the K loop, not the MFMAs.
+    unsigned *s_w = reinterpret_cast<unsigned *>(s_in);
 #pragma unroll
     for (int t = 0; t < N_IN; ++t) {
         const int i = threadIdx.x + 256 * t;
         const int c = i / (ITH * ROWW), r = (i / ROWW) % ITH, q = i % ROWW;
-        if (i < 3 * ITH * ROWW) s_in[(q & 1) * PLANE + (c * ITH + r) * PH + (q >> 1)] = vin[t] * x_scale;
+        const float v = vin[t] * x_scale;
+        const _Float16 vh = (_Float16)v;
+        const _Float16 vl = (_Float16)(v - (float)vh);
+        const unsigned word = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+        if (i < 3 * ITH * ROWW) s_w[(q & 1) * PLANE + (c * ITH + r) * PH + (q >> 1)] = word;
     }
     __syncthreads();
 
@@ -113,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
+        __builtin_amdgcn_sched_barrier(0);               // the weight loads of step s stay in step s (hoisted, they spill)
         f16x8 ah[NOB], al[NOB];
 #pragma unroll
         for (int b = 0; b < NOB; ++b) {
@@ -125,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
         const int ro = half ? ro1 : ro0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float *pe = s_in + xbase[t] + ro;      // even plane: kx = 0, 2, 4, 6
-            const float *po = pe + PLANE;                // odd plane:  kx = 1, 3, 5, (7: zero weight)
+            const unsigned *pe = s_w + xbase[t] + ro;    // even plane: kx = 0, 2, 4, 6
+            const unsigned *po = pe + PLANE;             // odd plane:  kx = 1, 3, 5, (7: zero weight)
             u32x4 bh, bl;
-            unsigned th, tl;
-            split2(pe[0], pe[1], th, tl); bh[0] = th; bl[0] = tl;
-            split2(pe[2], pe[3], th, tl); bh[1] = th; bl[1] = tl;
-            split2(po[0], po[1], th, tl); bh[2] = th; bl[2] = tl;
-            split2(po[2], po[3], th, tl); bh[3] = th; bl[3] = tl;
+            // word = hi | lo << 16: the hi halves of two words -> one fp16 pair of xh, the lo halves -> one pair of xl
+            bh[0] = __builtin_amdgcn_perm(pe[1], pe[0], 0x05040100u); bl[0] = __builtin_amdgcn_perm(pe[1], pe[0], 0x07060302u);
+            bh[1] = __builtin_amdgcn_perm(pe[3], pe[2], 0x05040100u); bl[1] = __builtin_amdgcn_perm(pe[3], pe[2], 0x07060302u);
+            bh[2] = __builtin_amdgcn_perm(po[1], po[0], 0x05040100u); bl[2] = __builtin_amdgcn_perm(po[1], po[0], 0x07060302u);
+            bh[3] = __builtin_amdgcn_perm(po[3], po[2], 0x05040100u); bl[3] = __builtin_amdgcn_perm(po[3], po[2], 0x07060302u);
             const f16x8 xh = __builtin_bit_cast(f16x8, bh), xl = __builtin_bit_cast(f16x8, bl);
 #pragma unroll
             for (int b = 0; b < NOB; ++b) {
@@ -143,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[b], xh, c, 0, 0, 0);
                 acc[t][b] = c;
             }
+            __builtin_amdgcn_sched_barrier(0);           // keeps the reads of the next fragment from being hoisted over 11 steps
         }
     }
 
@@ -161,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int oc = b * OCB + 8 * (r >> 2) + (r & 3) + 4 * half;
-                    const float v = fmaxf(fmaf(acc[t][b][r] * (oscale[oc] * x_inv), scale[oc], shift[oc]), 0.0f);
+                    const f32x4 pr = *reinterpret_cast<const f32x4 *>(s_par + 4 * oc);
+                    const float v = fmaxf(fmaf(acc[t][b][r] * pr[0], pr[1], pr[2]), 0.0f);
                     s_conv[oc * CONV_PITCH + p] = inside ? v : 0.0f;
                 }
         }
@@ -197,7 +217,7 @@ hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscal
     if (n > 65535 || !in_range || !oscale) return hipErrorInvalidValue;
     const int ph = h / 4, pw = wd / 4;
     const int tiles = ((ph + PTH - 1) / PTH) * ((pw + PTW - 1) / PTW);
-    const size_t lds = (size_t)S_ALL * sizeof(float);
+    const size_t lds = (size_t)(S_ALL + 4 * NOB * OCB) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
