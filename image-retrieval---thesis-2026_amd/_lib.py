@@ -78,6 +78,7 @@ SYMBOLS = {
     "mirx_conv1x1_bn_relu_split2h_terms": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "mirx_conv3x3_direct_terms_nchw_mfma16": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "mirx_transition_bn_relu_pool_conv1x1_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp,
                                                            ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),

@@ -10,7 +10,7 @@
 // takes 0.747 ms instead of 0.727 (28: 0.229 / 0.222, 14: 0.073 / 0.065).  Busy cycles x clock is the same for both: what the
 // power limit fixes is the rate of delivered fp16 FLOP *with their operand traffic* (54-56 KiB of ds_read_b128 per wave and
 // stage either way), and the cheaper instruction shape buys nothing once every operand comes from LDS.  k_conv3x3_d2p stays
-// the default; this file is the A/B arm (-DMIRX_CONV3X3_TERMS_MFMA=16 on mirx_api.hip).
+// the default; this file is the A/B arm (mirx_conv3x3_direct_terms_nchw_mfma16).
 //
 //   D[pixel, oc] += X[pixel, k] * Wt[k, oc]      A rows = 16 output pixels, B columns = 16 output channels, K = 32
 //

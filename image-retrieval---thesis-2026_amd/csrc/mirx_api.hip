@@ -773,9 +773,9 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
     return MIRX_OK;
 }
 
-int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
-                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
-                                   int64_t out_plane_stride, void *stream) {
+static int conv3x3_terms_impl(bool mfma16, const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
+                              float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                              int64_t out_plane_stride, void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
     MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms: side must be 56, 28 or 14");
     MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
@@ -785,19 +785,30 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
     MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms: output batch stride too small");
     MIRX_CHECK((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0,
                "conv3x3_terms: out must be 16-byte aligned and the batch stride a multiple of 4 floats");
-#ifndef MIRX_CONV3X3_TERMS_MFMA
-#define MIRX_CONV3X3_TERMS_MFMA 32   // 16: k_conv3x3_d2q on v_mfma_f32_16x16x32_f16 (the A/B arm: higher clock, same time)
-#endif
-#if MIRX_CONV3X3_TERMS_MFMA == 16
-    MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
-                                reinterpret_cast<hipStream_t>(stream)));
-#else
-    MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
-                                reinterpret_cast<hipStream_t>(stream)));
-#endif
+    if (mfma16) {
+        MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                    side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                    reinterpret_cast<hipStream_t>(stream)));
+    } else {
+        MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                    side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                    reinterpret_cast<hipStream_t>(stream)));
+    }
     return MIRX_OK;
+}
+
+int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                   int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                   int64_t out_plane_stride, void *stream) {
+    return conv3x3_terms_impl(false, y_terms, w2, oscale, n, side, out, out_batch_stride, y_inv, out_range_or_null,
+                              out_plane_stride, stream);
+}
+
+int mirx_conv3x3_direct_terms_nchw_mfma16(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
+                                          float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                          int64_t out_plane_stride, void *stream) {
+    return conv3x3_terms_impl(true, y_terms, w2, oscale, n, side, out, out_batch_stride, y_inv, out_range_or_null,
+                              out_plane_stride, stream);
 }
 
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,

@@ -119,7 +119,7 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
 // k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
-// k_conv3x3_d2q.hip: the same on v_mfma_f32_16x16x32_f16 (A/B arm, -DMIRX_CONV3X3_TERMS_MFMA=16; `out` 16-byte aligned)
+// k_conv3x3_d2q.hip: the same on v_mfma_f32_16x16x32_f16 (A/B arm: mirx_conv3x3_direct_terms_nchw_mfma16; `out` 16-byte aligned)
 hipError_t launch_conv3x3_d2q(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
 

@@ -243,6 +243,11 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
                                    int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                                    int64_t out_plane_stride, void *stream);
+/* The same contract on v_mfma_f32_16x16x32_f16 (k_conv3x3_d2q.hip): the A/B arm of the power-limit study -- the clock under
+ * it is 1.6 instead of 1.3 GHz, the layer takes the same time.  Kept callable so that it stays tested. */
+int mirx_conv3x3_direct_terms_nchw_mfma16(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
+                                          float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                          int64_t out_plane_stride, void *stream);
 
 /*
  * Range-publishing forms of the DenseNet producers (the two-fp16-term kernels need the range of what they read; see

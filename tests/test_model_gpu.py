@@ -575,7 +575,8 @@ def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
 @pytest.mark.parametrize("side,batch,cin,mag,pad", [(56, 2, 64, 1.0, 0), (28, 3, 256, 25.0, 0), (14, 5, 512, 1e-2, 0),
                                                     (14, 1, 1008, 1.0, 0), (14, 3, 512, 1.0, 28), (28, 2, 128, 3.0, 16),
                                                     (56, 1, 96, 1.0, 32)])
-def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad):
+@pytest.mark.parametrize("entry", ["mirx_conv3x3_direct_terms_nchw", "mirx_conv3x3_direct_terms_nchw_mfma16"])
+def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad, entry):
     """conv1x1 -> pre-split fp16-term bottleneck -> conv3x3 (mirx_conv1x1_bn_relu_split2h_terms +
     mirx_conv3x3_direct_terms_nchw) against a float64 dense layer relu(bn2(conv1(relu(bn1(x))))) -> conv2: 3e-6 of the
     largest output at any input magnitude; the halo ring of the DMA-staged strips is zero (out-of-range buffer loads);
@@ -612,8 +613,8 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad):
                                                       float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv),
                                                       ps if pad else 0, None), "terms")
     rng_before = float(brange.max())
-    _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), batch, side, vp(store, 4 * cin * ps), ctot * ps,
-                                                  vp(yinv), vp(brange), ps if pad else 0, None), "conv3x3_terms")
+    _lib.check(getattr(lib, entry)(vp(y), vp(c3), vp(c3osc), batch, side, vp(store, 4 * cin * ps), ctot * ps, vp(yinv), vp(brange),
+                                   ps if pad else 0, None), "conv3x3_terms")
     torch.cuda.synchronize()
     x64 = torch.relu(buf[:, :cin].double().cpu() * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None])
     y64 = torch.relu(torch.einsum("oc,bchw->bohw", w1.double().cpu(), x64) + b1.double().cpu()[None, :, None, None])
