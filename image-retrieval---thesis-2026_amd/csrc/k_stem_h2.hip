@@ -36,6 +36,11 @@ constexpr int CONV_PITCH = 260;              // 255 pixels + pad, 260 = 4 (mod 3
 constexpr int S_IN = 2 * PLANE;
 constexpr int S_CONV = NOB * OCB * CONV_PITCH;
 constexpr int S_ALL = S_IN > S_CONV ? S_IN : S_CONV;
+constexpr int W_BYTES = NOB * NSTEP * 2 * OCB * 16 * 2;      // all weights of the stem: 44 pieces of 1 KiB
+constexpr int W_OFF = S_IN * 4;                              // behind the patch (the conv tile reuses both after the K loop)
+constexpr int PAR_OFF = (W_OFF + W_BYTES > S_ALL * 4 ? W_OFF + W_BYTES : S_ALL * 4);   // epilogue constants behind everything
+constexpr int LDS_BYTES = PAR_OFF + 4 * NOB * OCB * 4;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
     const f32x2 v = {a, b};
@@ -67,42 +72,64 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     range_scales(range_read(in_range), x_scale, x_inv);
     // per-channel epilogue constants (accumulator scale, norm0 scale and shift) once per workgroup: the epilogue reads them
     // from LDS instead of three cached global loads per accumulator register
-    float *s_par = sm + S_ALL;           // [64][4]: oscale * 2^-s, scale, shift
+    float *s_par = sm + PAR_OFF / 4;     // [64][4]: oscale * 2^-s, scale, shift
     if (threadIdx.x < NOB * OCB) {
         s_par[4 * threadIdx.x] = oscale[threadIdx.x] * x_inv;
         s_par[4 * threadIdx.x + 1] = scale[threadIdx.x];
         s_par[4 * threadIdx.x + 2] = shift[threadIdx.x];
     }
 
+    // ---- the 44 KiB of weights go global -> LDS by DMA once per workgroup (11 one-KiB pieces per wave, issued before the
+    // patch loads; the region behind the patch is free until the conv tile is written after the K loop).  Every wave needs
+    // every weight: read per wave from L2 (the first version) that is 176 KiB per workgroup through a vector L1 the set does
+    // not fit in -- ten times the bytes of the input patch.  Piece = (channel block, step, term) = [32 oc][16 k] fp16; lane l
+    // -> LDS (row l / 2, slot l & 1) <- source chunk (l & 1) ^ ((row >> 3) & 1): conflict-free ds_read_b128 fragments.
+    char *s_wt = reinterpret_cast<char *>(sm) + W_OFF;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln = threadIdx.x & 63;
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w3, 0, W_BYTES, 0x00020000);
+        const int voff = (ln >> 1) * 32 + (((ln & 1) ^ ((ln >> 4) & 1)) << 4);
+#pragma unroll
+        for (int i = 0; i < W_BYTES / 1024 / 4; ++i) {
+            const int piece = wv + 4 * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(s_wt + piece * 1024), 16, voff, piece * 1024, 0, 0);
+        }
+    }
+
     // ---- patch staging: all global loads of a thread are issued before its first LDS store ---------------------
-    // element i -> (channel, row, column of a 36-wide row: columns 35 = kx 7 of the last pixel is written as zero);
-    // coalesced along the row, written to the plane of its column parity
-    constexpr int ROWW = 36;
-    constexpr int N_IN = (3 * ITH * ROWW + 255) / 256;           // 17 per thread
+    // (channel, row, column of a 36-wide row: column 35 = kx 7 of the last pixel is written as zero); coalesced along the row,
+    // written to the plane of its column parity.  Thread -> (row slot tid / 36, column q = tid % 36) once; pass t covers patch rows 7 t .. 7 t + 6 of the 3 x 39 (channel,
+    // row) pairs: the column, its bounds check and its parity plane are per-thread constants and the address advances by a
+    // constant per pass (the first version recomputed (c, r, q) from a flat index with two divisions per element).
+    constexpr int ROWW = 36, RPP = 7;                            // 7 x 36 = 252 of the 256 threads carry an element
+    constexpr int N_IN = (3 * ITH + RPP - 1) / RPP;              // 17 passes
+    const int s_row = threadIdx.x / ROWW, s_q = threadIdx.x % ROWW;
+    const int xx = ix0 + s_q;
+    const bool col_ok = s_row < RPP && s_q < ITW && xx >= 0 && xx < wd;
+    const bool lane_live = s_row < RPP;
     float vin[N_IN];
 #pragma unroll
     for (int t = 0; t < N_IN; ++t) {
-        const int i = threadIdx.x + 256 * t;
-        const int c = i / (ITH * ROWW), r = (i / ROWW) % ITH, q = i % ROWW;
-        const int yy = iy0 + r, xx = ix0 + q;
+        const int row = RPP * t + s_row;                         // (channel, patch row) pair
+        const int c = (row >= ITH) + (row >= 2 * ITH), r = row - c * ITH;
+        const int yy = iy0 + r;
         vin[t] = 0.0f;
-        if (i < 3 * ITH * ROWW && q < ITW && yy >= 0 && yy < h && xx >= 0 && xx < wd)
-            vin[t] = xi[((int64_t)c * h + yy) * wd + xx];
+        if (col_ok && row < 3 * ITH && yy >= 0 && yy < h) vin[t] = xi[((int64_t)c * h + yy) * wd + xx];
     }
+    unsigned *s_w = reinterpret_cast<unsigned *>(s_in);
     // The patch is split into its two fp16 terms HERE, once per input value, and stored as one 32-bit word (hi | lo << 16)
     // in the slot the fp32 value used to take: a B fragment is then 8 word reads and 8 v_perm_b32 -- a value is part of ~11
     // fragments, and splitting it in every one of them (~30 VALU instructions per fragment) bounded the K loop, not the MFMAs.
-    unsigned *s_w = reinterpret_cast<unsigned *>(s_in);
+    const int s_dst = (s_q & 1) * PLANE + s_row * PH + (s_q >> 1);
 #pragma unroll
     for (int t = 0; t < N_IN; ++t) {
-        const int i = threadIdx.x + 256 * t;
-        const int c = i / (ITH * ROWW), r = (i / ROWW) % ITH, q = i % ROWW;
         const float v = vin[t] * x_scale;
         const _Float16 vh = (_Float16)v;
         const _Float16 vl = (_Float16)(v - (float)vh);
         const unsigned word = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
-        if (i < 3 * ITH * ROWW) s_w[(q & 1) * PLANE + (c * ITH + r) * PH + (q >> 1)] = word;
+        if (lane_live && RPP * t + s_row < 3 * ITH) s_w[s_dst + RPP * t * PH] = word;   // row (c ITH + r) = 7 t + slot
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's weight pieces have landed (the barrier: everyone's)
     __syncthreads();
 
     // ---- implicit GEMM: wave -> pixel blocks 2 wave, 2 wave + 1 (32 pixels each) -----------------------------------
@@ -116,11 +143,11 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
         const int r = p / CTW, q = p % CTW;
         xbase[t] = 2 * r * PH + q;                       // + row offset of (c, ky) + j (+ PLANE for odd kx)
     }
-    // A fragments: w3[oc block][step][term][oc = n][16 k], this lane's 16 bytes at k = 8 half.  Both channel blocks run
+    // A fragments: LDS image of w3[oc block][step][term][oc = n][16 k], this lane's 16 bytes at k = 8 half.  Both channel blocks run
     // in this workgroup: the B fragment of a (pixel block, step) is split ONCE (the ~40 VALU instructions of the split,
     // not the three MFMAs of one block, bounded the one-block version) and feeds 2 x 3 MFMAs.
-    const uint16_t *wp = w3 + (int64_t)n * 16 + 8 * half;
-    constexpr int WBLK = NSTEP * 2 * OCB * 16;           // fp16 elements of one channel block's weights
+    const char *wp = s_wt + n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
+    constexpr int WBLK = NSTEP * 2 * 1024;               // bytes of one channel block's weights
     f32x16 acc[2][NOB];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -130,12 +157,11 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-        __builtin_amdgcn_sched_barrier(0);               // the weight loads of step s stay in step s (hoisted, they spill)
         f16x8 ah[NOB], al[NOB];
 #pragma unroll
         for (int b = 0; b < NOB; ++b) {
-            ah[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 0) * OCB * 16);
-            al[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 1) * OCB * 16);
+            ah[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 0) * 1024);
+            al[b] = *reinterpret_cast<const f16x8 *>(wp + b * WBLK + (s * 2 + 1) * 1024);
         }
         // this k-group's (c, ky) row: 2 s + half, row 21 (zero weights) re-reads row 20
         const int rho0 = 2 * s, rho1 = 2 * s + 1 < 21 ? 2 * s + 1 : 20;
@@ -167,24 +193,30 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
 
     // ---- BN + ReLU, conv tile to LDS (register r: channel 8 (r >> 2) + (r & 3) + 4 half, pixel n) ---
     __syncthreads();                                     // every wave is done with the patch
+    {
+        int pp[2];
+        bool live[2], inside[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int p = (2 * wave + t) * 32 + n;
-        if (p < NPX) {
-            const int r0 = p / CTW, q = p % CTW;
+        for (int t = 0; t < 2; ++t) {
+            pp[t] = (2 * wave + t) * 32 + n;
+            live[t] = pp[t] < NPX;
+            const int r0 = pp[t] / CTW, q = pp[t] % CTW;
             const int cy = cy0 + r0, cx = cx0 + q;
             // outside the conv map = pool padding; 0 never wins over a relu output
-            const bool inside = cy >= 0 && cy < ch && cx >= 0 && cx < cw;
-#pragma unroll
-            for (int b = 0; b < NOB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int oc = b * OCB + 8 * (r >> 2) + (r & 3) + 4 * half;
-                    const f32x4 pr = *reinterpret_cast<const f32x4 *>(s_par + 4 * oc);
-                    const float v = fmaxf(fmaf(acc[t][b][r] * pr[0], pr[1], pr[2]), 0.0f);
-                    s_conv[oc * CONV_PITCH + p] = inside ? v : 0.0f;
-                }
+            inside[t] = cy >= 0 && cy < ch && cx >= 0 && cx < cw;
         }
+#pragma unroll
+        for (int b = 0; b < NOB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = b * OCB + 8 * (r >> 2) + (r & 3) + 4 * half;
+                const f32x4 pr = *reinterpret_cast<const f32x4 *>(s_par + 4 * oc);      // once for both pixel blocks
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float v = fmaxf(fmaf(acc[t][b][r] * pr[0], pr[1], pr[2]), 0.0f);
+                    if (live[t]) s_conv[oc * CONV_PITCH + pp[t]] = inside[t] ? v : 0.0f;
+                }
+            }
     }
     __syncthreads();
 
@@ -217,7 +249,7 @@ hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscal
     if (n > 65535 || !in_range || !oscale) return hipErrorInvalidValue;
     const int ph = h / 4, pw = wd / 4;
     const int tiles = ((ph + PTH - 1) / PTH) * ((pw + PTW - 1) / PTW);
-    const size_t lds = (size_t)(S_ALL + 4 * NOB * OCB) * sizeof(float);
+    const size_t lds = LDS_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
