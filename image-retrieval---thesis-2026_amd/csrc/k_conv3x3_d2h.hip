@@ -283,19 +283,22 @@ hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, i
 // (l & 1) ^ ((pixel >> 3) & 1)); a lane's source offset is its pixel's position inside the image, or an offset beyond the
 // buffer's num_records for the padding ring (out-of-range buffer loads return zero: the halo needs no branch and no
 // pre-zeroed LDS).  Weights by DMA as in k_conv3x3_d2h.  The tap loop is k_conv3x3_d2h's.
-template <int W, int R>
+// IPW > 1 (7 x 7 maps): a workgroup takes IPW whole images (R = W), each with its own zero ring, so that its 7 column blocks
+// are as full as on the larger maps (4 x 49 = 196 pixels)
+template <int W, int R, int IPW = 1>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
                                                         const float *__restrict__ oscale, float *__restrict__ out,
                                                         int64_t out_bs, const float *__restrict__ in_inv,
-                                                        unsigned *__restrict__ out_range, int64_t out_ps) {
+                                                        unsigned *__restrict__ out_range, int64_t out_ps, int64_t n_img) {
     constexpr int PW = W + 2, PR = R + 2;     // padded strip
-    constexpr int NPIX = PR * PW;             // padded pixels of a stage
+    static_assert(IPW == 1 || R == W, "several images per workgroup: whole images only");
+    constexpr int NPIX = IPW * PR * PW;       // padded pixels of a stage
     constexpr int NP = (NPIX + 31) / 32;      // 1-KiB DMA pieces per term plane
     constexpr int PLANE = NP * 32 * 32;       // bytes of one term of one stage (32 B per pixel, rounded up to whole pieces)
     constexpr int STAGE = 2 * PLANE;
     constexpr int WSTAGE = 9 * 2 * COUT * KC * 2;   // bytes of one stage of weights (18 KiB): 18 pieces of 1 KiB
     constexpr int W_LDS0 = 2 * STAGE;               // weight buffers behind the two activation buffers
-    constexpr int NOUT = R * W;               // output pixels of a full strip
+    constexpr int NOUT = IPW * R * W;         // output pixels of a full strip
     constexpr int NBLK = (NOUT + 31) / 32;    // 7
     static_assert(NBLK <= 8, "two column blocks per wave");
     constexpr int PPW = (2 * NP + 3) / 4;     // activation pieces per wave and stage (both terms)
@@ -319,8 +322,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     }
     const int oy0 = strip * R;                                // first output row of the strip
     constexpr unsigned IMG_BYTES = 16u * W * W * 32u;        // 8 groups x 2 terms x W*W pixels x 32 B
+    img *= IPW;                                               // first image of this workgroup
+    const int n_here = (int)(n_img - img < IPW ? n_img - img : IPW);   // images that exist (the batch's tail)
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(yt + img * (int64_t)(IMG_BYTES / 2)), 0,
-                                                                           IMG_BYTES, 0x00020000);
+                                                                           (unsigned)n_here * IMG_BYTES, 0x00020000);
     // this wave's activation pieces: q = wave + 4 i over the 2 NP pieces of a stage (term = q / NP, piece = q % NP); the
     // source offset of this lane inside a term plane, or "out of range" for the zero ring
     unsigned a_src[PPW];
@@ -330,11 +335,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
         const int q = wave + 4 * i;
         const int term = q / NP, piece = q % NP;
         const int pix = piece * 32 + (lane >> 1);
-        const int pr = pix / PW, pc = pix % PW;
+        const int ji = pix / (PR * PW), prem = pix % (PR * PW);    // image of the workgroup, padded pixel inside it
+        const int pr = prem / PW, pc = prem % PW;
         const int iy = oy0 - 1 + pr, ix = pc - 1;
         const bool inside = q < 2 * NP && pix < NPIX && iy >= 0 && iy < W && ix >= 0 && ix < W;
         const int chunk = (lane & 1) ^ ((pix >> 3) & 1);
-        a_src[i] = inside ? (unsigned)((term * W * W + iy * W + ix) * 32 + chunk * 16) : 0xfffffff0u;
+        // images beyond the batch lie beyond num_records: zero like the padding ring
+        a_src[i] = inside ? (unsigned)(ji * IMG_BYTES + (term * W * W + iy * W + ix) * 32 + chunk * 16) : 0xfffffff0u;
         a_dst[i] = q < 2 * NP ? term * PLANE + piece * 1024 : -1;
     }
     auto dma_a = [&](int st, int buf) {
@@ -355,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
         live_blk[t] = blk < NBLK;                              // wave-uniform
         int p = blk * 32 + n;
         if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
-        pbase[t] = (p / W) * PW + (p % W);
+        const int pj = p / (R * W), pq = p % (R * W);          // image of the workgroup (0 unless IPW > 1), pixel inside it
+        pbase[t] = pj * (PR * PW) + (pq / W) * PW + (pq % W);
     }
     const int a_off = n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w3, 0, NST * WSTAGE, 0x00020000);
@@ -447,36 +455,38 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
 
     // ---- outputs straight from the accumulators: register r = channel 8 (r >> 2) + (r & 3) + 4 half, lane = pixel ----
     const float x_inv = in_inv[0];
-    float *oi = out + img * out_bs + (int64_t)oy0 * W;
+    float *oi = out + img * out_bs + (int64_t)oy0 * W;        // IPW > 1: image j of the workgroup at + j * out_bs
     float osc[16], vmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int p = (wave + 4 * t) * 32 + n;
-        if (live_blk[t] && p < NOUT && oy0 + p / W < W) {
+        const int pj = p / (R * W), pq = p % (R * W);
+        if (live_blk[t] && p < NOUT && pj < n_here && oy0 + pq / W < W) {
+            float *op = oi + (int64_t)pj * out_bs + pq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
                 const float v = acc[t][r] * osc[r];
                 vmax = range_max(vmax, v);
-                oi[(int64_t)oc * out_ps + p] = v;
+                op[(int64_t)oc * out_ps] = v;
             }
         }
     }
     if (out_range) range_publish(out_range, vmax, lane);
 }
 
-template <int W, int R>
+template <int W, int R, int IPW = 1>
 hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
                       const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
-    constexpr int NP = ((R + 2) * (W + 2) + 31) / 32;
+    constexpr int NP = (IPW * (R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_conv3x3_d2p<W, R>), dim3((W + R - 1) / R, (unsigned)n), dim3(256), lds, st, yt, w2, oscale, out,
-                       out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps);
+    hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(256), lds, st, yt,
+                       w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);
     return hipGetLastError();
 }
 
@@ -501,6 +511,7 @@ hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const floa
     if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 7) return launch_d2p<7, 7, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     return hipErrorInvalidValue;
 }
 

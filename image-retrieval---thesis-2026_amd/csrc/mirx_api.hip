@@ -777,14 +777,14 @@ static int conv3x3_terms_impl(bool mfma16, const void *y_terms, const void *w2, 
                               float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                               int64_t out_plane_stride, void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
-    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms: side must be 56, 28 or 14");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14 || (side == 7 && !mfma16),
+               "conv3x3_terms: side must be 56, 28, 14 or 7 (mfma16 arm: 56, 28, 14)");
     MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
     if (!out_plane_stride) out_plane_stride = (int64_t)side * side;
-    MIRX_CHECK(out_plane_stride >= (int64_t)side * side && out_plane_stride % 4 == 0,
-               "conv3x3_terms: the plane stride is 0 (= side^2) or a multiple of 4 that is at least side^2");
+    MIRX_CHECK(out_plane_stride >= (int64_t)side * side, "conv3x3_terms: the plane stride is 0 (= side^2) or at least side^2");
     MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms: output batch stride too small");
-    MIRX_CHECK((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0,
-               "conv3x3_terms: out must be 16-byte aligned and the batch stride a multiple of 4 floats");
+    MIRX_CHECK(!mfma16 || ((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0 && out_plane_stride % 4 == 0),
+               "conv3x3_terms (mfma16 arm, 16-byte stores): out 16-byte aligned, batch and plane strides multiples of 4 floats");
     if (mfma16) {
         MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
                                     side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,

@@ -218,7 +218,7 @@ def _plane_stride(side):
     ps = PLANE_STRIDE_H2.get(side, hw)
     if CONV3X3_KERNEL_H2.get(side, "wino") != "terms":
         return hw
-    assert ps >= hw and ps % 4 == 0
+    assert ps == hw or (ps > hw and ps % 4 == 0)
     return ps
 
 
@@ -227,8 +227,8 @@ def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None):
     _plane_stride) already holds the first block.cin channels and `brange` (64 range slots) bounds them.  Every layer on
     the 56 / 28 / 14 maps: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT
     into fp16 terms, scaled by a bound it derives from brange before it runs (2^-t goes to the layer's row of `lranges`);
-    conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange.  7 x 7 maps:
-    fp32 bottleneck + fp32 Winograd."""
+    conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange (7 x 7 maps: four
+    images per workgroup).  CONV3X3_KERNEL_H2 "direct2h" / "wino": fp32 bottleneck + in-kernel split / fp32 Winograd."""
     lib = _lib.load()
     b, _, ps = buf.shape
     h = w = side
@@ -489,7 +489,7 @@ CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-l
 # Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations in "range slots" (include/mirx.h,
 # mirx_conv1x1_bn_relu_split2h); kernels per map side must publish ranges: "terms", "direct2h" or "wino" (fp32 Winograd).
 SPLIT2H_DENSENET = True
-CONV3X3_KERNEL_H2 = {56: "terms", 28: "terms", 14: "terms", 7: "wino"}       # "terms": pre-split bottleneck (see _dense_block_h2)
+CONV3X3_KERNEL_H2 = {56: "terms", 28: "terms", 14: "terms", 7: "terms"}      # "terms": pre-split bottleneck (see _dense_block_h2)
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
@@ -880,7 +880,7 @@ class DenseNet121(nn.Module):
 
     def _features_h2(self, x, cache):
         """-> feature map before norm5 [B, 1024, 7, 7]; every convolution on the matrix pipe with two fp16 terms per
-        operand (7 x 7 maps' 3x3 convs: fp32 Winograd), ranges carried in range slots."""
+        operand, ranges carried in range slots."""
         f = self.densenet121[0]
         lib = _lib.load()
         h2 = cache.get("h2") or self._prepare_h2(cache)

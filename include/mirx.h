@@ -232,7 +232,8 @@ int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch
  *       (y_ks = max_o sum_c |W[o, c]|, y_kb = max |bias|: a bound known before the kernel runs) is brought into
  *       [2^14, 2^15); y_inv_out[0] receives 2^-t.
  *   mirx_conv3x3_direct_terms_nchw: mirx_conv3x3_direct_split2h_nchw reading such y_terms and y_inv; the padding ring of the
- *       staged strip comes from out-of-range buffer loads (zero), w2 in the permuted channel order.
+ *       staged strip comes from out-of-range buffer loads (zero), w2 in the permuted channel order.  side 56 / 28 / 14, and
+ *       7 (four whole images per workgroup, each with its own zero ring).
  *   x_plane_stride / out_plane_stride: floats between consecutive channel planes of the dense block's buffer (0 = packed,
  *       hw resp. side^2; see mirx_conv1x1_bn_relu_split2h).
  */

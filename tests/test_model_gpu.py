@@ -574,7 +574,8 @@ def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
 @pytest.mark.gpu
 @pytest.mark.parametrize("side,batch,cin,mag,pad", [(56, 2, 64, 1.0, 0), (28, 3, 256, 25.0, 0), (14, 5, 512, 1e-2, 0),
                                                     (14, 1, 1008, 1.0, 0), (14, 3, 512, 1.0, 28), (28, 2, 128, 3.0, 16),
-                                                    (56, 1, 96, 1.0, 32)])
+                                                    (56, 1, 96, 1.0, 32), (7, 5, 512, 1.0, 0), (7, 1, 992, 1.0, 0),
+                                                    (7, 8, 640, 30.0, 0), (7, 3, 512, 1.0, 15)])
 @pytest.mark.parametrize("entry", ["mirx_conv3x3_direct_terms_nchw", "mirx_conv3x3_direct_terms_nchw_mfma16"])
 def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad, entry):
     """conv1x1 -> pre-split fp16-term bottleneck -> conv3x3 (mirx_conv1x1_bn_relu_split2h_terms +
@@ -585,6 +586,8 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad, entr
     import ctypes
     from mirx import _lib
     from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
+    if side == 7 and entry.endswith("mfma16"):
+        pytest.skip("the 16x16x32 arm covers the 56 / 28 / 14 maps")
     lib = _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(side + cin)

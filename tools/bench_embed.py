@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
     ap.add_argument("--no-fused-transition", action="store_true", help="DenseNet: separate bn+relu+avgpool pass before the transition conv")
-    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14 maps (terms | direct2h | wino)")
+    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14/7 maps (terms | direct2h | wino), e.g. terms,terms,terms,wino")
     a = ap.parse_args()
     if a.no_split3_linear:
         import mirx.model as mm
@@ -42,7 +42,7 @@ def main():
     if a.no_fused_transition:
         mm.FUSED_TRANSITION_POOL = False
     if a.conv3x3:
-        for side_, kind_ in zip((56, 28, 14), a.conv3x3.split(',')):
+        for side_, kind_ in zip((56, 28, 14, 7), a.conv3x3.split(',')):
             mm.CONV3X3_KERNEL_H2[side_] = kind_
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
