@@ -555,6 +555,42 @@ def test_split2h_path_matches_oracle_and_legacy(model_and_sd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["padded_planes", "fused_transition", "wino7", "direct2h_14", "wino_28"])
+def test_alternative_h2_configurations_agree(model_and_sd, variant):
+    """The measured-and-parked arms of the two-fp16-term path stay correct: padded channel planes, the one-launch
+    transition, fp32 Winograd on the 7 x 7 maps, in-kernel-split direct conv, Winograd on a middle map -- each against the
+    default configuration on the same weights (2e-6) and the CPU restatement (1e-5)."""
+    import mirx.model as mm
+    m, sd = model_and_sd
+    x = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    x[3] *= 12.0
+    saved = (dict(mm.PLANE_STRIDE_H2), mm.FUSED_TRANSITION_POOL, dict(mm.CONV3X3_KERNEL_H2))
+    with torch.no_grad():
+        base = m(x.cuda()).cpu()
+        try:
+            if variant == "padded_planes":
+                mm.PLANE_STRIDE_H2.update({28: 800, 14: 224})
+            elif variant == "fused_transition":
+                mm.FUSED_TRANSITION_POOL = True
+            elif variant == "wino7":
+                mm.CONV3X3_KERNEL_H2[7] = "wino"
+            elif variant == "direct2h_14":
+                mm.CONV3X3_KERNEL_H2[14] = "direct2h"
+            elif variant == "wino_28":
+                mm.CONV3X3_KERNEL_H2[28] = "wino"
+            alt = m(x.cuda()).cpu()
+        finally:
+            mm.PLANE_STRIDE_H2.clear()
+            mm.PLANE_STRIDE_H2.update(saved[0])
+            mm.FUSED_TRANSITION_POOL = saved[1]
+            mm.CONV3X3_KERNEL_H2.clear()
+            mm.CONV3X3_KERNEL_H2.update(saved[2])
+        ref = OD.embed(x, sd)
+    assert float((alt - base).abs().max()) <= 2e-6
+    assert float((alt - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
     """the bench embeds 2048 images per stream -- other grid sizes, 64-bit strides, and (two-fp16 path) a
     range that is the maximum over the WHOLE batch.  The same 6 images embedded alone and as rows of a 2048-image batch
