@@ -15,8 +15,8 @@
 // The epilogue publishes the largest |output| in `out_amax` the same way.
 //
 // Contract otherwise as mirx_conv1x1_bn_relu_split3: y = act_out(W * act_in(x) + bias), NCHW, tile 128 output
-// channels x 128 pixels, 16-channel stages, double-buffered LDS (32 KiB), weights by LDS DMA, activations
-// register-prefetched.  w2 = [cout / 128][cin / 16][2 terms][128 out][16 in] fp16.
+// channels x 128 (small launches) or 2 x 128 pixels, 16-channel stages, double-buffered LDS (32 / 48 KiB), weights by LDS
+// DMA, activations register-prefetched.  w2 = [cout / 128][cin / 16][2 terms][128 out][16 in] fp16.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -35,10 +35,16 @@ constexpr int CP = 128;            // pixels per workgroup
 constexpr int KC = 16;             // channels per stage
 constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage (4 KiB)
 constexpr int PLANE_B = CP * KC * 2;
-constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;   // 16 KiB
+#ifndef MIRX_C1H2_NPT
+#define MIRX_C1H2_NPT 2             // pixel tiles per workgroup on large launches (1: the A/B arm)
+#endif
 
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, bool POOL>
-__global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+// NPT = pixel tiles (of 128) per workgroup.  NPT = 2: both tiles run against ONE staged copy of the weights -- the weight
+// stage (8 KiB per 16 channels) is as many bytes as a pixel tile's activations, so one tile per workgroup pulls twice the
+// layer's bytes into the CU; two tiles halve the L2 -> LDS weight stream and the weight-fragment reads per MFMA, at 128
+// accumulator registers per lane (two workgroups per CU instead of three).
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, bool POOL, int NPT>
+__global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w2,
@@ -54,7 +60,9 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
-    const int64_t p0 = (int64_t)blockIdx.x * CP;
+    static_assert(NPT == 1 || !POOL, "the pooling prologue runs one pixel tile per workgroup");
+    constexpr int STAGE_N = 2 * PLANE_A + NPT * 2 * PLANE_B;       // bytes of one LDS stage
+    const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT);
     const int co0 = blockIdx.y * CM;
     const int nk = cin / KC;
 
@@ -78,16 +86,18 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
     // POOL (transitions): x is the un-pooled map [.., 2 ph, 2 pw]; a staged value is the average of relu(bn(.)) over the 2 x 2
     // input pixels of output pixel (oy, ox) -- the norm + relu + avgpool pass and its pooled tensor disappear
     const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw; POOL: >= 4 hw)
-    int64_t b_off = 0;
-    {
-        const int64_t pp = p0 + b_px;
+    const float *xsrc[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        int64_t b_off = 0;
+        const int64_t pp = p0 + u * CP + b_px;
         if (pp < total) {
             const int64_t o = pp % hw;
             b_off = (pp / hw) * xbs + (POOL ? (2 * (o / pool_w)) * (int64_t)(2 * pool_w) + 2 * (o % pool_w) : o);
         }
+        xsrc[u] = x + b_off + (int64_t)(8 * b_kg) * in_hw;
     }
-    const float *xsrc = x + b_off + (int64_t)(8 * b_kg) * in_hw;
-    const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + term * PLANE_B
+    const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + tile * 2 PLANE_B + term * PLANE_B
     // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
     // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
     // l / 2, slot l & 1), which holds source chunk (l & 1) ^ ((row >> 3) & 1) -- the same for every piece.
@@ -98,56 +108,35 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE + piece * 1024), 16, w_voff,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE_N + piece * 1024), 16, w_voff,
                                                      kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
         }
     };
 
-#ifndef MIRX_C1H2_W_DMA
-#define MIRX_C1H2_W_DMA 1      // 0: weights through registers (plain loads + ds_write_b128), the A/B arm
-#endif
-    // A/B arm, weights through registers: thread t copies 16-byte chunk (row t / 2, slot t & 1) of both term planes.  With plain
-    // loads only, hipcc's own counted s_waitcnt (vmcnt(19) .. vmcnt(10) in the ISA) keeps the loads of stage kt + 2 in flight
-    // across the barrier of stage kt + 1 -- two stages of reads per workgroup instead of the one the DMA version can have
-    // (it must drain with vmcnt(0), see below).  Measured: isolated layers at 1024 images 2-4 % faster on the 28 / 14 maps,
-    // 6 % slower on the 7 maps; the whole forward (B = 4096, two streams) 1.2 % SLOWER (42.7 vs 43.2 k img/s, same box) --
-    // the layers are not latency-bound either.  A build with one MFMA per product instead of three (MIRX_C1H2_EXP_ONE_MFMA)
-    // gains 5-7 %: not matrix-bound.  What is left is the memory system itself at 3.4-4.9 TB/s with a 1.25 GHz shader clock.
-    const int wq_row = threadIdx.x >> 1, wq_slot = threadIdx.x & 1;
-    const char *wsrc = reinterpret_cast<const char *>(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)) + wq_row * 32 +
-                       ((wq_slot ^ ((wq_row >> 3) & 1)) << 4);
-    const int wq_lds = wq_row * 32 + wq_slot * 16;
-    u32x4 wa[2], wb[2];
-    [[maybe_unused]] auto load_w = [&](int kt, u32x4 (&w)[2]) {
-        w[0] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (2 * CM * KC * 2));
-        w[1] = *reinterpret_cast<const u32x4 *>(wsrc + (int64_t)kt * (2 * CM * KC * 2) + CM * KC * 2);
-    };
-    [[maybe_unused]] auto store_w = [&](int buf, const u32x4 (&w)[2]) {
-        *reinterpret_cast<u32x4 *>(sm + buf * STAGE + wq_lds) = w[0];
-        *reinterpret_cast<u32x4 *>(sm + buf * STAGE + PLANE_A + wq_lds) = w[1];
-    };
-
+    // (An arm with the weights through registers -- plain loads + ds_write_b128, so that hipcc's counted s_waitcnt keeps two
+    // stages of loads in flight across the barrier instead of the vmcnt(0) the DMA needs -- measured 2-4 % faster on isolated
+    // 28 / 14 layers, 6 % slower on the 7 maps and 1.2 % SLOWER on the whole forward: the layers are not latency-bound.  A
+    // build with one MFMA per product instead of three (MIRX_C1H2_EXP_ONE_MFMA) gains 5-7 %: not matrix-bound either.)
     // TWO register sets: the activation loads of stage kt + 2 are issued while stage kt computes and stage kt + 1
     // waits in the other set.  With one set a workgroup has 8 KiB of HBM reads in flight (32 KiB per CU at four
     // workgroups): by Little's law that caps the layer near 4 TB/s, which is where the one-set kernel sat.
     constexpr int NR = POOL ? 32 : 8;                   // raw values per thread and stage
-    float ra[NR], rb[NR], sca[8], sha[8], scb[8], shb[8];
-    auto load = [&](int kt, float (&r)[NR], float (&rsc)[8], float (&rsh)[8]) {
+    float ra[NPT][NR], rb[NPT][NR], sca[8], sha[8], scb[8], shb[8];
+    auto load = [&](int kt, float (&r)[NPT][NR], float (&rsc)[8], float (&rsh)[8]) {
         if constexpr (POOL) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float *pj = xsrc + ((int64_t)kt * KC + j) * in_hw;
+                const float *pj = xsrc[0] + ((int64_t)kt * KC + j) * in_hw;
                 const f32x2 t0 = *reinterpret_cast<const f32x2 *>(pj);
                 const f32x2 t1 = *reinterpret_cast<const f32x2 *>(pj + 2 * pool_w);
-                r[4 * j] = t0[0]; r[4 * j + 1] = t0[1]; r[4 * j + 2] = t1[0]; r[4 * j + 3] = t1[1];
+                r[0][4 * j] = t0[0]; r[0][4 * j + 1] = t0[1]; r[0][4 * j + 2] = t1[0]; r[0][4 * j + 3] = t1[1];
             }
         } else {
+            // (`nt` loads here, to keep the weights L2-resident, measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images)
 #pragma unroll
-#ifdef MIRX_C1H2_NT_LOADS      // experiment (measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images): `nt` activation loads so that the weights stay L2-resident
-        for (int j = 0; j < 8; ++j) r[j] = __builtin_nontemporal_load(&xsrc[((int64_t)kt * KC + j) * in_hw]);
-#else
-        for (int j = 0; j < 8; ++j) r[j] = xsrc[((int64_t)kt * KC + j) * in_hw];
-#endif
+            for (int u = 0; u < NPT; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
         }
         if (PROLOGUE) {
 #pragma unroll
@@ -157,43 +146,47 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
             }
         }
     };
-    auto store = [&](int buf, const float (&r)[NR], const float (&rsc)[8], const float (&rsh)[8]) {
-        char *sb = sm + buf * STAGE;
-        // two fp16 terms of each (scaled) value, two values at a time (round to nearest even)
-        u32x4 ph, pl;
+    auto store = [&](int buf, const float (&r)[NPT][NR], const float (&rsc)[8], const float (&rsh)[8]) {
+        char *sb = sm + buf * STAGE_N;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2 v;
-            if constexpr (POOL) {
+        for (int u = 0; u < NPT; ++u) {
+            // two fp16 terms of each (scaled) value, two values at a time (round to nearest even)
+            u32x4 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int c = 2 * j + e;
-                    const float s0 = fmaxf(fmaf(r[4 * c], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[4 * c + 1], rsc[c], rsh[c]), 0.f);
-                    const float s1 = fmaxf(fmaf(r[4 * c + 2], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[4 * c + 3], rsc[c], rsh[c]), 0.f);
-                    v[e] = (s0 + s1) * 0.25f;
+            for (int j = 0; j < 4; ++j) {
+                f32x2 v;
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = 2 * j + e;
+                        const float s0 = fmaxf(fmaf(r[u][4 * c], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[u][4 * c + 1], rsc[c], rsh[c]), 0.f);
+                        const float s1 = fmaxf(fmaf(r[u][4 * c + 2], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[u][4 * c + 3], rsc[c], rsh[c]), 0.f);
+                        v[e] = (s0 + s1) * 0.25f;
+                    }
+                } else {
+                    v[0] = r[u][2 * j];
+                    v[1] = r[u][2 * j + 1];
+                    if (PROLOGUE) {
+                        v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
+                        v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
+                    }
                 }
-            } else {
-                v[0] = r[2 * j];
-                v[1] = r[2 * j + 1];
-                if (PROLOGUE) {
-                    v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
-                    v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
-                }
+                v = v * x_scale;
+                const f16x2 h = __builtin_convertvector(v, f16x2);
+                const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+                const f16x2 l = __builtin_convertvector(r1, f16x2);
+                ph[j] = __builtin_bit_cast(unsigned, h);
+                pl[j] = __builtin_bit_cast(unsigned, l);
             }
-            v = v * x_scale;
-            const f16x2 h = __builtin_convertvector(v, f16x2);
-            const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
-            const f16x2 l = __builtin_convertvector(r1, f16x2);
-            ph[j] = __builtin_bit_cast(unsigned, h);
-            pl[j] = __builtin_bit_cast(unsigned, l);
+            *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B) = ph;
+            *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B + PLANE_B) = pl;
         }
-        *reinterpret_cast<u32x4 *>(sb + b_lds) = ph;
-        *reinterpret_cast<u32x4 *>(sb + b_lds + PLANE_B) = pl;
     };
 
     // ---- fragment addressing: lane -> row (lane & 31), K chunk (lane >> 5) -------------------------------
     const int kg = lane >> 5;
-    int fa[2], fb[2];
+    constexpr int NN = 2 * NPT;                        // accumulator tiles along the pixels: ni = 2 * pixel tile + t
+    int fa[2], fb[2];                                  // fb: + (ni >> 1) * 2 PLANE_B for the pixel tile
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int ra_ = wm * 64 + t * 32 + (lane & 31);
@@ -202,11 +195,11 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         fb[t] = 2 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NN];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -215,37 +208,34 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         sOsc[threadIdx.x] = oscale[co0 + threadIdx.x] * x_inv;
     }
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
-    auto stage = [&](int kt, int cur, float (&rnext)[NR], float (&scn)[8], float (&shn)[8], u32x4 (&wnext)[2],
-                     const float (&rstore)[NR], const float (&scs)[8], const float (&shs)[8], const u32x4 (&wstore)[2]) {
+    auto stage = [&](int kt, int cur, float (&rnext)[NPT][NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NPT][NR],
+                     const float (&scs)[8], const float (&shs)[8]) {
         // stage kt visible: this wave's weight DMA of stage kt has landed.  vmcnt(0), NOT a counted wait: the two DMA
         // pieces are older than the 8 activation loads issued behind them, and `vmcnt(8)` was tried to keep those loads
         // in flight across the barrier -- it produced state-dependent results (embeddings off by 2e-5 once the caches
         // were warm: the LDS-DMA pieces were still landing when the count had already dropped to 8), i.e. LDS-DMA and
         // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
         // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
-#if MIRX_C1H2_W_DMA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
-#else
-        __syncthreads();
-        load_w(kt + 2 < nk ? kt + 2 : nk - 1, wnext);
-#endif
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
-        const char *sb = sm + cur * STAGE;
-        f16x8 a[2][2], b[2][2];
+        const char *sb = sm + cur * STAGE_N;
+        f16x8 a[2][2], b[NN][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                a[t][p] = *reinterpret_cast<const f16x8 *>(sb + fa[t] + p * PLANE_A);
-                b[t][p] = *reinterpret_cast<const f16x8 *>(sb + fb[t] + p * PLANE_B);
-            }
+            for (int p = 0; p < 2; ++p) a[t][p] = *reinterpret_cast<const f16x8 *>(sb + fa[t] + p * PLANE_A);
+#pragma unroll
+        for (int ni = 0; ni < NN; ++ni)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                b[ni][p] = *reinterpret_cast<const f16x8 *>(sb + fb[ni & 1] + (ni >> 1) * 2 * PLANE_B + p * PLANE_B);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < NN; ++ni) {
                 f32x16 c = acc[mi][ni];
                 // smallest terms first
 #ifndef MIRX_C1H2_EXP_ONE_MFMA          // diagnostic build (wrong results, timing only): one MFMA per product block
@@ -256,33 +246,20 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
                 acc[mi][ni] = c;
             }
         store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
-#if !MIRX_C1H2_W_DMA
-        store_w(cur ^ 1, wstore);
-#endif
     };
-#if MIRX_C1H2_W_DMA
     dma_w(0, 0);
-#else
-    load_w(0, wa);
-#endif
     load(0, ra, sca, sha);
-#if !MIRX_C1H2_W_DMA
-    load_w(nk > 1 ? 1 : 0, wb);
-#endif
     load(nk > 1 ? 1 : 0, rb, scb, shb);
     store(0, ra, sca, sha);
-#if !MIRX_C1H2_W_DMA
-    store_w(0, wa);
-#endif
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        stage(kt, 0, ra, sca, sha, wa, rb, scb, shb, wb);
-        stage(kt + 1, 1, rb, scb, shb, wb, ra, sca, sha, wa);
+        stage(kt, 0, ra, sca, sha, rb, scb, shb);
+        stage(kt + 1, 1, rb, scb, shb, ra, sca, sha);
     }
-    if (kt < nk) stage(kt, 0, ra, sca, sha, wa, rb, scb, shb, wb);
+    if (kt < nk) stage(kt, 0, ra, sca, sha, rb, scb, shb);
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
-    // pixel p0 + 64 wn + 32 ni + (lane & 31)
+    // pixel p0 + 128 (ni >> 1) + 64 wn + 32 (ni & 1) + (lane & 31)
     float vmax = 0.f;
     if (YTERMS) {
         // y as the 3x3 conv wants it: [image][group g of 16 channels][term][pixel][16] fp16, where group g = 4 wm + 2 mi +
@@ -291,8 +268,8 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         // a half-wave 1 KiB
         uint16_t *yt = reinterpret_cast<uint16_t *>(y);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
+        for (int ni = 0; ni < NN; ++ni) {
+            const int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
             if (pp >= total) continue;
             const int64_t bimg = pp / hw, off = pp % hw;
 #pragma unroll
@@ -326,8 +303,8 @@ __global__ __launch_bounds__(256, POOL ? 2 : 3) void k_conv1x1_h2(const float *_
         return;
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int64_t pp = p0 + wn * 64 + 32 * ni + (lane & 31);
+    for (int ni = 0; ni < NN; ++ni) {
+        const int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
         if (pp >= total) continue;
         const int64_t bimg = pp / hw, off = pp % hw;
         float *yo = y + bimg * ybs + off;
@@ -360,26 +337,34 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     if (!xps) xps = pool_w ? 4 * (int64_t)hw : hw;     // compact channel planes
     if (!yps) yps = hw;
     if (xps < (pool_w ? 4 * (int64_t)hw : hw) || yps < hw) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((n * (int64_t)hw + CP - 1) / CP), (unsigned)(cout / CM));
-    const size_t lds = 2 * (size_t)STAGE;
+    // two pixel tiles per workgroup (one staged copy of the weights for both) when the launch still fills the chip
+    const int64_t px = n * (int64_t)hw;
+    const int npt = (!pool_w && px >= (int64_t)2 * CP * 512) ? MIRX_C1H2_NPT : 1;
+    const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
+    const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
-#define MIRX_H2C(P, R, T, L)                                                                               \
+#define MIRX_H2K(P, R, T, L, N)                                                                            \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, L>),       \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, L, N>),    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, L>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, L, N>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
                            n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, pool_w, xps, yps); \
     }
-    if (pool_w) {
-        MIRX_H2C(true, false, false, true)
-    } else if (yterms) {
-        MIRX_H2C(true, true, true, false)
-    } else if (scale) {
-        if (relu_out) MIRX_H2C(true, true, false, false) else MIRX_H2C(true, false, false, false)
-    } else {
-        if (relu_out) MIRX_H2C(false, true, false, false) else MIRX_H2C(false, false, false, false)
+#define MIRX_H2C(P, R, T)                                                                                  \
+    {                                                                                                      \
+        if (npt == 2) MIRX_H2K(P, R, T, false, 2) else MIRX_H2K(P, R, T, false, 1)                          \
     }
+    if (pool_w) {
+        MIRX_H2K(true, false, false, true, 1)
+    } else if (yterms) {
+        MIRX_H2C(true, true, true)
+    } else if (scale) {
+        if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)
+    } else {
+        if (relu_out) MIRX_H2C(false, true, false) else MIRX_H2C(false, false, false)
+    }
+#undef MIRX_H2K
 #undef MIRX_H2C
     return hipGetLastError();
 }
