@@ -285,8 +285,14 @@ hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, i
 // pre-zeroed LDS).  Weights by DMA as in k_conv3x3_d2h.  The tap loop is k_conv3x3_d2h's.
 // IPW > 1 (7 x 7 maps): a workgroup takes IPW whole images (R = W), each with its own zero ring, so that its 7 column blocks
 // are as full as on the larger maps (4 x 49 = 196 pixels)
-template <int W, int R, int IPW = 1>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
+// NW = waves per workgroup.  NW = 8 (-DMIRX_D2P_WAVES=8, the A/B arm): one workgroup takes twice the pixels (a strip of twice
+// the rows, or twice the images) against ONE staged copy of the weights -- a stage of weights (18 KiB) is almost as many bytes
+// as a 4-row strip's activations (22 KiB), so the 4-wave version pulls 80 KiB into the CU per 8 rows of a 56 x 56 map where
+// this one pulls 56.  Parity-identical and SLOWER: 0.95 vs 0.75 ms per 56 x 56 layer, 44.3 vs 45.1 k img/s on the forward --
+// with a single workgroup per CU all eight waves meet at every stage barrier and nothing else feeds the matrix pipe, which
+// is what bounds this kernel (unlike the 1x1 conv, where sharing the weight stage between two pixel tiles gained 2.5 %).
+template <int W, int R, int IPW = 1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
                                                         const float *__restrict__ oscale, float *__restrict__ out,
                                                         int64_t out_bs, const float *__restrict__ in_inv,
                                                         unsigned *__restrict__ out_range, int64_t out_ps, int64_t n_img) {
@@ -300,8 +306,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     constexpr int W_LDS0 = 2 * STAGE;               // weight buffers behind the two activation buffers
     constexpr int NOUT = IPW * R * W;         // output pixels of a full strip
     constexpr int NBLK = (NOUT + 31) / 32;    // 7
-    static_assert(NBLK <= 8, "two column blocks per wave");
-    constexpr int PPW = (2 * NP + 3) / 4;     // activation pieces per wave and stage (both terms)
+    static_assert(NBLK <= 2 * NW, "two column blocks per wave");
+    constexpr int PPW = (2 * NP + NW - 1) / NW;   // activation pieces per wave and stage (both terms)
+    constexpr int WPW = (18 + NW - 1) / NW;       // weight pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) char sm[];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -326,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     const int n_here = (int)(n_img - img < IPW ? n_img - img : IPW);   // images that exist (the batch's tail)
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(yt + img * (int64_t)(IMG_BYTES / 2)), 0,
                                                                            (unsigned)n_here * IMG_BYTES, 0x00020000);
-    // this wave's activation pieces: q = wave + 4 i over the 2 NP pieces of a stage (term = q / NP, piece = q % NP); the
+    // this wave's activation pieces: q = wave + NW i over the 2 NP pieces of a stage (term = q / NP, piece = q % NP); the
     // source offset of this lane inside a term plane, or "out of range" for the zero ring
     unsigned a_src[PPW];
     int a_dst[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int q = wave + 4 * i;
+        const int q = wave + NW * i;
         const int term = q / NP, piece = q % NP;
         const int pix = piece * 32 + (lane >> 1);
         const int ji = pix / (PR * PW), prem = pix % (PR * PW);    // image of the workgroup, padded pixel inside it
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     bool live_blk[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int blk = wave + 4 * t;
+        const int blk = wave + NW * t;
         live_blk[t] = blk < NBLK;                              // wave-uniform
         int p = blk * 32 + n;
         if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
@@ -370,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
     auto dma_w = [&](int st, int buf) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int piece = wave + 4 * i;               // 18 pieces: waves 0, 1 take five, waves 2, 3 four
+        for (int i = 0; i < WPW; ++i) {
+            const int piece = wave + NW * i;              // 18 pieces dealt round-robin to the waves
             if (piece < 18)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + W_LDS0 + buf * WSTAGE + piece * 1024), 16, w_voff,
                                                          st * WSTAGE + piece * 1024, 0, 0);
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int p = (wave + 4 * t) * 32 + n;
+        const int p = (wave + NW * t) * 32 + n;
         const int pj = p / (R * W), pq = p % (R * W);
         if (live_blk[t] && p < NOUT && pj < n_here && oy0 + pq / W < W) {
             float *op = oi + (int64_t)pj * out_bs + pq;
@@ -477,16 +484,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_d2p(const uint16_t *__restri
     if (out_range) range_publish(out_range, vmax, lane);
 }
 
-template <int W, int R, int IPW = 1>
+template <int W, int R, int IPW = 1, int NW = 4>
 hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
                       const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
     constexpr int NP = (IPW * (R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW>),
+    static_assert((size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2 <= 160 * 1024, "LDS of one CU");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(256), lds, st, yt,
-                       w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);
+    hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW, NW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(64 * NW), lds,
+                       st, yt, w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);
     return hipGetLastError();
 }
 
@@ -508,10 +516,20 @@ hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const floa
     if (n > 65535 || !in_inv || !oscale) return hipErrorInvalidValue;
     if (!out_ps) out_ps = (int64_t)side * side;
     if (out_ps < (int64_t)side * side) return hipErrorInvalidValue;
+#ifndef MIRX_D2P_WAVES
+#define MIRX_D2P_WAVES 4          // 8: one 8-wave workgroup per CU on twice the pixels (the A/B arm, measured slower)
+#endif
+#if MIRX_D2P_WAVES == 8
+    if (side == 56) return launch_d2p<56, 8, 1, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 28) return launch_d2p<28, 14, 1, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 14) return launch_d2p<14, 14, 2, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 7) return launch_d2p<7, 7, 8, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+#else
     if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 7) return launch_d2p<7, 7, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+#endif
     return hipErrorInvalidValue;
 }
 
