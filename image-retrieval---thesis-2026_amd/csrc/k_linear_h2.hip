@@ -8,6 +8,9 @@
 // fp16 has 5 exponent bits, so the CALLER supplies range information: the weights arrive multiplied by a power of two
 // (mirx.model._linear_h2_weights: largest |w| in [2^13, 2^14)), x is multiplied by the power of two `x_scale` while it
 // is staged, and the accumulator by `out_scale` = 1 / (x_scale * w_scale) before bias / activation -- all exact.
+// (Two token tiles per workgroup against one staged copy of the weights -- the change that gave the DenseNet 1x1 conv 6 % --
+// was built here too and measured 7-10 % SLOWER on all three token-major backbones: 212 VGPRs, two workgroups per CU instead
+// of three, and this kernel lives on the matrix pipe, not on the bytes it pulls in.)
 // Contract: |x * x_scale| <= 65504 for every element (mirx.model uses it where a bound is provable: the inputs that
 // come out of a LayerNorm).  Everything else (tiling, DMA'd weight stages, paired x loads, XCD-contiguous tile order,
 // epilogues) is k_linear_s3's.
