@@ -1453,4 +1453,9 @@ def build_model(model_type, embedding_dim=None, **kw):
         return DinoV2(embedding_dim=embedding_dim, **kw), 518
     if model_type == "medsiglip":
         return MedSigLIP(embed_dim=embedding_dim if embedding_dim is not None else 512, **kw), 448
+    if model_type in ("resnet50", "convnextv2_sra"):
+        # named in the reference's MODEL_CONFIGS (collection names) and kept there for compatibility, but not on the hot path
+        # SURVEY section 8 scopes (DenseNet-121, ConvNeXtV2, DINOv2, MedSigLIP): no MI355X-native forward exists for them
+        raise ValueError(f"Unknown model type: {model_type} (outside the accelerated path: build it with the reference's own "
+                         f"model.py and feed its embeddings to MilvusRetriever / FlatIndex)")
     raise ValueError(f"Unknown model type: {model_type}")
