@@ -591,6 +591,32 @@ def test_alternative_h2_configurations_agree(model_and_sd, variant):
 
 
 @pytest.mark.gpu
+def test_concurrent_forwards_on_two_streams_equal_the_sequential_result(model_and_sd):
+    """bench.py embeds the two halves of a micro-batch concurrently on two HIP streams (same module, shared weight caches).
+    The halves must come out bit-identical to the same halves embedded one after the other on the default stream -- a
+    missing dependency between the streams (range slots, scratch buffers, cached weights) would show here."""
+    m, _ = model_and_sd
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(512, 3, 224, 224, generator=g, device="cuda")
+    x[300:] *= 7.0                                             # different ranges in the two halves
+    with torch.no_grad():
+        seq = torch.cat([m(x[:256]), m(x[256:])], 0)
+        torch.cuda.synchronize()
+        out = torch.empty_like(seq)
+        cur = torch.cuda.current_stream()
+        side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(3):                                   # a few rounds: the streams drift against each other
+            for j, st in enumerate(side):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    out[256 * j:256 * (j + 1)] = m(x[256 * j:256 * (j + 1)])
+            for st in side:
+                cur.wait_stream(st)
+            torch.cuda.synchronize()
+            assert torch.equal(out, seq), rep
+
+
+@pytest.mark.gpu
 def test_densenet_rows_do_not_depend_on_the_batch(model_and_sd):
     """the bench embeds 2048 images per stream -- other grid sizes, 64-bit strides, and (two-fp16 path) a
     range that is the maximum over the WHOLE batch.  The same 6 images embedded alone and as rows of a 2048-image batch
