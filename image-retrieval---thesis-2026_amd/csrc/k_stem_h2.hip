@@ -61,8 +61,23 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     float *s_conv = sm;                  // [OCB][CONV_PITCH], after the K loop
     const int ph = h / 4, pw = wd / 4, ch = h / 2, cw = wd / 2;
     const int tiles_x = (pw + PTW - 1) / PTW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x % tiles_x;
-    const int64_t img = blockIdx.y;
+    // XCD-aware order (as in k_conv3x3_d2p): workgroups are dealt to the 8 XCDs round-robin in linear order, so with (tile,
+    // image) = blockIdx the neighbouring tiles of an image -- whose input patches overlap by a quarter in each direction and
+    // whose 28-byte output row segments share 128-byte lines -- would sit behind eight different L2s.  Re-dealt, XCD x walks
+    // images x, x + 8, .. tile by tile: the overlap is an L2 hit and the partial output lines merge in one L2.
+    int tile = blockIdx.x;
+    int64_t img = blockIdx.y;
+#ifndef MIRX_STEM_PLAIN_ORDER
+    {
+        const unsigned ntile = gridDim.x, lin = blockIdx.x + ntile * blockIdx.y, full = gridDim.y & ~7u;
+        if (lin < ntile * full) {
+            const unsigned j = lin >> 3;
+            tile = (int)(j % ntile);
+            img = (int64_t)(j / ntile) * 8 + (lin & 7);
+        }
+    }
+#endif
+    const int tile_y = tile / tiles_x, tile_x = tile % tiles_x;
     const int oc0 = 0;
     const int py0 = tile_y * PTH, px0 = tile_x * PTW;
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv row/col of the tile
@@ -155,8 +170,11 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
         for (int b = 0; b < NOB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
+#ifndef MIRX_STEM_EXP
+#define MIRX_STEM_EXP 0            // diagnostic builds (wrong results, timing only): 1 no K loop, 2 no conv-tile epilogue, 4 no pooling
+#endif
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
+    for (int s = 0; s < ((MIRX_STEM_EXP & 1) ? 0 : NSTEP); ++s) {
         f16x8 ah[NOB], al[NOB];
 #pragma unroll
         for (int b = 0; b < NOB; ++b) {
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
 
     // ---- BN + ReLU, conv tile to LDS (register r: channel 8 (r >> 2) + (r & 3) + 4 half, pixel n) ---
     __syncthreads();                                     // every wave is done with the patch
-    {
+    if (!(MIRX_STEM_EXP & 2)) {
         int pp[2];
         bool live[2], inside[2];
 #pragma unroll
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     // ---- max-pool 3x3 / 2: only the pooled map goes to HBM ----------------------------------------
     float *yi = y + img * y_bs + oc0 * (int64_t)ph * pw;   // y_bs: batch stride (the dense block's buffer)
     float vmax = 0.f;
-    for (int i = threadIdx.x; i < NOB * OCB * PTH * 8; i += 256) {
+    for (int i = threadIdx.x; i < ((MIRX_STEM_EXP & 4) ? 0 : NOB * OCB * PTH * 8); i += 256) {
         const int oc = i / (PTH * 8), r = (i / 8) % PTH, q = i % 8;
         const int py = py0 + r, px = px0 + q;
         if (q < PTW && py < ph && px < pw) {
