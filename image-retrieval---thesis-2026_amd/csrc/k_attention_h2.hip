@@ -55,17 +55,38 @@ __device__ inline void split8(const float (&v)[8], bf16x8 &h, bf16x8 &l) {
         C = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, C, 0, 0, 0);             \
     }
 
+// XCD-aware order: workgroups are dealt to the 8 XCDs round-robin in linear order (x fastest), so the query tiles of one
+// (image, head) -- which all stream the same K and V -- would sit behind eight different L2s.  Re-dealt, XCD x takes the
+// (image, head) pairs x, x + 8, .. query tile by query tile: K / V of a pair cross the fabric once.  (Any bijection is correct.)
+__device__ inline void attention_block(int &qt, int &head, int64_t &img) {
+    qt = blockIdx.x;
+    head = blockIdx.y;
+    img = blockIdx.z;
+#ifndef MIRX_ATT_PLAIN_ORDER
+    const unsigned nqt = gridDim.x, npair = gridDim.y * gridDim.z, full = npair & ~7u;
+    const unsigned lin = blockIdx.x + nqt * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin < nqt * full) {
+        const unsigned j = lin >> 3;
+        const unsigned pair = (j / nqt) * 8 + (lin & 7);
+        qt = (int)(j % nqt);
+        head = (int)(pair % gridDim.y);
+        img = pair / gridDim.y;
+    }
+#endif
+}
+
 __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict__ qkv, int n, int heads,
                                                          float q_mul, float k_mul, float v_mul, float s_inv, float o_inv,
                                                          float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) char sm[2 * BUF];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, nq = lane & 31;
-    const int head = blockIdx.y;
-    const int64_t img = blockIdx.z;
+    int qt, head;
+    int64_t img;
+    attention_block(qt, head, img);
     const int64_t tok = 3 * (int64_t)heads * DH;                          // floats per token in qkv
     const float *base = qkv + img * n * tok + head * DH;                   // q of token t: base + t*tok; k: + heads*DH; v: + 2*heads*DH
-    const int q_idx = blockIdx.x * 128 + wave * 32 + nq;
+    const int q_idx = qt * 128 + wave * 32 + nq;
     const int q_ld = q_idx < n ? q_idx : n - 1;
 
     // this lane's query: channels 16 ks + 8 half + i, pre-multiplied by scale * log2(e), three terms each
@@ -243,11 +264,12 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
     extern __shared__ __attribute__((aligned(16))) char smg[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, nq = lane & 31;
-    const int head = blockIdx.y;
-    const int64_t img = blockIdx.z;
+    int qt, head;
+    int64_t img;
+    attention_block(qt, head, img);
     const int64_t tok = 3 * (int64_t)heads * DH;
     const float *base = qkv + img * n * tok + head * DH;
-    const int q_idx = blockIdx.x * 128 + wave * 32 + nq;
+    const int q_idx = qt * 128 + wave * 32 + nq;
     const int q_ld = q_idx < n ? q_idx : n - 1;
 
     bf16x8 qh[KS], ql[KS];
