@@ -35,6 +35,9 @@ constexpr int CP = 128;            // pixels per workgroup
 constexpr int KC = 16;             // channels per stage
 constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage (4 KiB)
 constexpr int PLANE_B = CP * KC * 2;
+#ifndef MIRX_C1H2_MIN_WG
+#define MIRX_C1H2_MIN_WG 256        // two-tile workgroups only when the launch has at least this many of them (one per CU; 512: -0.3 %)
+#endif
 #ifndef MIRX_C1H2_NPT
 #define MIRX_C1H2_NPT 2             // pixel tiles per workgroup on large launches (1: the A/B arm)
 #endif
@@ -339,7 +342,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     if (xps < (pool_w ? 4 * (int64_t)hw : hw) || yps < hw) return hipErrorInvalidValue;
     // two pixel tiles per workgroup (one staged copy of the weights for both) when the launch still fills the chip
     const int64_t px = n * (int64_t)hw;
-    const int npt = (!pool_w && px >= (int64_t)2 * CP * 512) ? MIRX_C1H2_NPT : 1;
+    const int npt = (!pool_w && px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG) ? MIRX_C1H2_NPT : 1;
     const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
