@@ -64,6 +64,7 @@ SYMBOLS = {
                                         _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
+    "mirx_grn_scale": (_int, [_vp, _vp, _i64, _int, ctypes.c_float, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv1x1_bn_relu_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64,
                                             _vp, ctypes.c_float, ctypes.c_float, _vp, _i64, _i64, _vp]),

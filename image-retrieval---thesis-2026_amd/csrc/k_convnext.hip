@@ -140,6 +140,33 @@ __global__ __launch_bounds__(256) void k_grn_apply(float *__restrict__ x, int64_
     }
 }
 
+// GRN scale vector: scale[b, c] = 1 + weight[c] * gx[b, c] / (mean_c gx[b, :] + eps), and the largest |scale| of the whole
+// batch into smax[0] (the two-fp16-term Linear that folds the scale into its staging reads it as its device-side bound):
+// unsigned atomic max on the float's bits (|scale| >= 0; NaN / inf sort above everything), smax zeroed by the caller.
+// One workgroup per image; replaces five ATen launches per ConvNeXt block.
+__global__ __launch_bounds__(256) void k_grn_scale(const float *__restrict__ gx, const float *__restrict__ weight, int c,
+                                                   float eps, float *__restrict__ scale, unsigned *__restrict__ smax) {
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *g = gx + (int64_t)blockIdx.x * c;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < c; i += 256) acc += g[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    const float inv = 1.f / (((red[0] + red[1]) + (red[2] + red[3])) / (float)c + eps);
+    float vmax = 0.f;
+    for (int i = threadIdx.x; i < c; i += 256) {
+        const float v = fmaf(weight[i], g[i] * inv, 1.f);
+        scale[(int64_t)blockIdx.x * c + i] = v;
+        vmax = range_max(vmax, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) vmax = range_max(vmax, __shfl_xor(vmax, off, 64));
+    if (lane == 0) atomicMax(smax, __float_as_uint(vmax));
+}
+
 }  // namespace
 
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
@@ -161,6 +188,14 @@ hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int
         hipLaunchKernelGGL((k_dwconv7<16, 2>), dim3((unsigned)tiles, (unsigned)((c + DCH - 1) / DCH), (unsigned)n),
                            dim3(256), lds, st, x, w, bias, c, h, wd, y);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *smax,
+                            hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535 || c < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_grn_scale, dim3((unsigned)n), dim3(256), 0, st, gx, weight, c, eps, scale, reinterpret_cast<unsigned *>(smax));
     return hipGetLastError();
 }
 

@@ -884,6 +884,14 @@ int mirx_grn_norm_nhwc(const float *x, int64_t n, int hw, int c, float *gx, void
     return MIRX_OK;
 }
 
+int mirx_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *scale_max,
+                   void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && c >= 1 && eps >= 0.f, "grn_scale: bad argument");
+    MIRX_CHECK(n == 0 || (gx && weight && scale && scale_max), "grn_scale: null buffer");
+    MIRX_HIP(launch_grn_scale(gx, weight, n, c, eps, scale, scale_max, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream) {
     MIRX_CHECK(n >= 0 && hw >= 1 && c >= 4 && c % 4 == 0 && (n == 0 || (x && scale && shift)),
                "grn_apply: c must be a multiple of 4");

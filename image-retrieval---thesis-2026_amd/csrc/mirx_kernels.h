@@ -47,6 +47,8 @@ hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int
                           float *y, hipStream_t st);
 // gx[b][c] = sqrt(sum over the hw positions of x[b][p][c]^2)       (x = [n][hw][c], channels last)
 hipError_t launch_grn_norm(const float *x, int64_t n, int hw, int c, float *gx, hipStream_t st);
+hipError_t launch_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *smax,
+                            hipStream_t st);
 // x[b][p][c] = x[b][p][c] * scale[b][c] + shift[c], in place
 hipError_t launch_grn_apply(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, hipStream_t st);
 

@@ -512,6 +512,7 @@ def _linear_w3(mod):
 
 
 SPLIT2H_LINEAR = True    # Linears fed by a LayerNorm: two fp16 terms per operand (3 MFMAs per product) instead of three bf16
+GRN_SCALE_KERNEL = True    # ConvNeXtV2: the GRN scale vector and its maximum in one HIP launch (False: five ATen launches)
 SPLIT2H_ATTENTION = True   # flash attention on two fp16 terms where q / k / v have provable bounds (else three bf16 terms)
 
 
@@ -1041,8 +1042,15 @@ class _CnxBlock(nn.Module):
             with torch.cuda.device(x.device):
                 st = _stream(x.device)
                 _lib.check(lib.mirx_grn_norm_nhwc(_ptr(hid), b, h * w, c4, _ptr(gx), st), "mirx_grn_norm_nhwc")
-                scale = torch.addcmul(torch.ones_like(gx), mlp.grn.weight.detach(),
-                                      gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
+                if GRN_SCALE_KERNEL:
+                    scale = torch.empty_like(gx)
+                    smax = torch.zeros(1, dtype=torch.float32, device=x.device)
+                    _lib.check(lib.mirx_grn_scale(_ptr(gx), _ptr(mlp.grn.weight.detach().reshape(-1).contiguous()), b, c4, 1e-6,
+                                                  _ptr(scale), _ptr(smax), st), "mirx_grn_scale")
+                else:                                                      # the ATen expression of the same vector (A/B)
+                    scale = torch.addcmul(torch.ones_like(gx), mlp.grn.weight.detach(),
+                                          gx / (gx.mean(dim=-1, keepdim=True) + 1e-6))
+                    smax = scale.abs().amax().reshape(1)
                 # GRN apply folded into the second Linear: the scale multiplies x while it is staged, the shift
                 # is constant per feature, so W (x s + b) + bias = W (x s) + (bias + W b)
                 hb = _linear_out_bound(self.norm, mlp.fc1)                 # |gelu(fc1(LN(.)))| <= |fc1(LN(.))| <= hb
@@ -1050,7 +1058,6 @@ class _CnxBlock(nn.Module):
                     # two fp16 terms: |hid * scale| <= hb * max |scale|; the second factor is data, so it stays on the
                     # device (one scalar) and the kernel derives its staging scale from it
                     w2, ws = _linear_h2_weights(mlp.fc2)
-                    smax = scale.abs().amax().reshape(1)
                     _lib.check(lib.mirx_linear_split2h_nchw(_ptr(hid), b, h * w, c4, _ptr(w2),
                                                             _ptr(self._fc2_bias_with_grn_shift()), c, _ptr(xc), _ptr(scale),
                                                             float(hb), _ptr(smax), 1.0 / ws, _ptr(out), st),

@@ -370,6 +370,12 @@ int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image
  * n <= 65535.  Fixed summation order (bit-reproducible).
  */
 int mirx_grn_norm_nhwc(const float *x, int64_t n, int hw, int c, float *gx, void *stream);
+/* The GRN scale vector in one launch: scale[b, j] = 1 + weight[j] * gx[b, j] / (mean_j gx[b, :] + eps)  (timm
+ * GlobalResponseNorm: x * (1 + weight * Nx) + bias with Nx = Gx / (mean Gx + eps), eps = 1e-6), and scale_max[0] = the largest
+ * |scale| over the batch -- the device-side bound mirx_linear_split2h_nchw reads; combined by atomic max, so the caller ZEROES
+ * scale_max[0] first. */
+int mirx_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *scale_max,
+                   void *stream);
 int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream);
 
 /*

@@ -191,6 +191,25 @@ def test_grn_kernels_match_torch(n, hw, c):
         float((y - (x * scale[:, None, :] + shift)).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("n,c", [(3, 512), (64, 4096), (1, 7), (5, 1031)])
+def test_grn_scale_kernel_matches_torch(n, c):
+    """mirx_grn_scale: 1 + weight * gx / (mean gx + eps) per image and the batch-wide max |scale| (the device-side bound of the
+    two-fp16-term block tail), against the torch expression of timm's GlobalResponseNorm."""
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n + c)
+    gx = (torch.rand(n, c, generator=g) * 5).to(dev)
+    w = torch.randn(c, generator=g).to(dev)
+    scale = torch.full((n, c), float("nan"), device=dev)
+    smax = torch.zeros(1, device=dev)                       # combined by atomic max: zeroed by the caller
+    _lib.check(lib.mirx_grn_scale(_vp(gx), _vp(w), n, c, 1e-6, _vp(scale), _vp(smax), None), "mirx_grn_scale")
+    torch.cuda.synchronize()
+    want = 1.0 + w.double() * (gx.double() / (gx.double().mean(dim=-1, keepdim=True) + 1e-6))
+    assert float((scale.double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    assert float(smax) == float(scale.abs().max())
+
+
 def test_convnext_block_fused_matches_module_path():
     import mirx.model as mm
     dev = torch.device("cuda:0")

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--no-split3-linear", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (tail overlap)")
     ap.add_argument("--no-split2h", action="store_true", help="DenseNet: the three-bf16-term path of round 1")
+    ap.add_argument("--no-grn-kernel", action="store_true", help="ConvNeXtV2: GRN scale vector through ATen")
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
     ap.add_argument("--no-fused-transition", action="store_true", help="DenseNet: separate bn+relu+avgpool pass before the transition conv")
@@ -35,6 +36,8 @@ def main():
     import mirx.model as mm
     if a.no_split2h:
         mm.SPLIT2H_DENSENET = False
+    if a.no_grn_kernel:
+        mm.GRN_SCALE_KERNEL = False
     if a.no_split2h_attention:
         mm.SPLIT2H_ATTENTION = False
     for kv in filter(None, a.plane_stride.split(",")):
