@@ -3,6 +3,7 @@
 resident 1M x 1024 gallery (BASELINE.json metric), on N GPUs of one node.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 20 --warmup 5          (starts its own 8 ranks: self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -66,6 +67,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--search-only", action="store_true", help="skip the embed stage (dev aid; not the metric)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="ranks only rendezvous (gloo) and print a line: exercises the self-launch path without a GPU")
     return ap.parse_args()
 
 
@@ -211,16 +214,68 @@ def extras(args, dev):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run
+    (127.0.0.1 rendezvous on a free port) BEFORE this process makes any GPU call, forward rank 0's JSON line and
+    return the children's exit code.  A child process, never an exec: this pool forbids replacing a process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env["MIRX_BENCH_CHILD"] = "1"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            lines.append(ln.strip())
+        else:
+            sys.stderr.write(ln)           # launcher chatter stays off the contract's stdout
+    rc = proc.wait()
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        rc = 3
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    return rc
+
+
+def launch_selftest(world, rank):
+    """--selftest-launch: what a rank does instead of the GPU bench when only the launch path is under test (CPU
+    container): gloo rendezvous, one all-reduce, rank 0 prints a line of the contract's shape."""
+    import torch.distributed as dist
+    if os.environ.get("MIRX_BENCH_SELFTEST_FAIL") == str(rank):
+        sys.exit(7)                                    # a rank that dies: the launcher must report it
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.float64) * (rank + 1)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest", "value": float(t.item()), "unit": "sum of ranks + 1", "n_gpus": world,
+                          "launch_selftest": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("MIRX_BENCH_CHILD") != "1":
+            sys.exit(self_launch(args))
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.selftest_launch:
+        launch_selftest(world, rank)
+        return
     import torch.distributed as dist
     from mirx import _lib
     from mirx.dist import ShardedSearcher, shard_bounds

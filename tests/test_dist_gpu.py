@@ -75,3 +75,26 @@ def test_two_rank_sharded_search_on_gpu():
         np.testing.assert_array_equal(i, o_i[r * ql:(r + 1) * ql])
         np.testing.assert_array_equal(s, o_s[r * ql:(r + 1) * ql])
         assert st["tier1_answered"] > 0                  # each 45k-row shard went through the MFMA tier
+
+
+def test_plain_bench_command_runs_two_ranks_in_rehearsal_mode():
+    """`python bench.py --gpus 2` as the driver types it (no torchrun): the script starts its own two ranks.  On this
+    one-GPU box both share cuda:0 and the collectives run over gloo (MIRX_BENCH_REHEARSE=1) -- the control flow, the
+    per-stage times and the single JSON line are what is checked; RCCL itself needs two GPUs (never run here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MIRX_BENCH_CHILD")}
+    env["MIRX_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--gallery", "80000", "--queries", "256", "--embed-batch", "256", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["queries_per_gpu_per_step"] == 256
+    assert set(d["config"]["pipeline_ms_per_step_max_over_ranks"]) == {"embed", "gather_q", "search", "gather_cand", "merge"}
+    assert d["config"]["search_stats_last_step"]["nq"] == 512        # every rank searches all ranks' queries
