@@ -63,25 +63,18 @@ SYMBOLS = {
     "mirx_linear_split2h_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,
                                         _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
-    "mirx_grn_apply_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "mirx_grn_scale": (_int, [_vp, _vp, _i64, _int, ctypes.c_float, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv1x1_bn_relu_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64,
                                             _vp, ctypes.c_float, ctypes.c_float, _vp, _i64, _i64, _vp]),
-    "mirx_stem_conv7_bn_relu_pool_split3_into": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp]),
-    "mirx_conv3x3_winograd_nchw_ranged": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp, _vp]),
-    "mirx_conv3x3_direct_split2h_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_layernorm": (_int, [_vp, _i64, _int, _vp, _vp, ctypes.c_float, _vp, _int, _vp]),
     "mirx_patchify_nchw": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, ctypes.c_float, _vp, _int, _vp]),
     "mirx_attention_small": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _int, _int, _int, ctypes.c_float, _vp, _vp]),
-    "mirx_range_absmax": (_int, [_vp, _i64, _vp, _vp]),
+    "mirx_range_absmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool_split2h_into": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split2h_terms": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
-    "mirx_conv3x3_direct_terms_nchw_mfma16": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
-    "mirx_transition_bn_relu_pool_conv1x1_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp,
-                                                           ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
@@ -99,6 +92,7 @@ SYMBOLS = {
 }
 
 _lib = None
+ABI_VERSION = 300          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():
@@ -118,6 +112,9 @@ def load():
             raise MirxError(f"libmirx.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.mirx_version() != ABI_VERSION:
+        raise MirxError(f"{LIB_PATH} is ABI version {lib.mirx_version()}, this package binds version {ABI_VERSION}: "
+                        f"rebuild with `make -C {os.path.join(_HERE, 'csrc')}`")
     _lib = lib
     return lib
 

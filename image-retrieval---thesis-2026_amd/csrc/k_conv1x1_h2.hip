@@ -4,15 +4,17 @@
 // Half the matrix-pipe time and 4 instead of 6 LDS bytes per element; the layer then runs against its HBM stream.
 //
 // fp16 has 5 exponent bits, so the kernel needs the RANGE of its input.  DenseNet activations have no a-priori bound,
-// so the range travels with the data: every kernel that writes into a dense block's buffer also publishes the largest
-// |value| it wrote (`amax` slots: 64 floats, slot = workgroup % 64, combined with an unsigned atomic max -- the bit
-// patterns of non-negative floats order like the floats).  This kernel reads the 64 slots of its input buffer, and
-//     bound = in_ks * max(slots) + in_kb      (in_ks = max |BN scale|, in_kb = max |BN shift| of the prologue; 1, 0 without)
-// is an upper bound of every value it stages; x_scale = the power of two with bound * x_scale in [2^14, 2^15).  A value
+// so the range travels with the data, PER IMAGE (mirx_common.h): every kernel that writes into a dense block's buffer
+// also folds the largest |value| it wrote for image b into the buffer's range row[b] (unsigned atomic max -- the bit
+// patterns of non-negative floats order like the floats).  This kernel reads row[b] of its input buffer, and
+//     bound_b = in_ks * row[b] + in_kb      (in_ks = max |BN scale|, in_kb = max |BN shift| of the prologue; 1, 0 without)
+// is an upper bound of every value of image b it stages; x_scale_b = the power of two with bound_b * x_scale_b in [2^14,
+// 2^15).  A pixel tile may straddle images: the scale belongs to the staging thread's pixel and, in the epilogue, to the
+// lane's pixel, so an image's result never depends on its batch mates.  A value
 // below 2^-18 of the bound keeps an ABSOLUTE error of 2^-40 of the bound (fp16 subnormal low term), everything else 22
 // bits.  The weights arrive pre-split with one power-of-two scale PER OUTPUT CHANNEL (largest |w| of the row in
 // [2^13, 2^14)); `oscale[o]` = 1 / that scale is applied to the accumulator together with 1 / x_scale -- all exact.
-// The epilogue publishes the largest |output| in `out_amax` the same way.
+// The epilogue folds the largest |output| of image b into `out_amax[b]` the same way.
 //
 // Contract otherwise as mirx_conv1x1_bn_relu_split3: y = act_out(W * act_in(x) + bias), NCHW, tile 128 output
 // channels x 128 (small launches) or 2 x 128 pixels, 16-channel stages, double-buffered LDS (32 / 48 KiB), weights by LDS
@@ -46,8 +48,8 @@ constexpr int PLANE_B = CP * KC * 2;
 // stage (8 KiB per 16 channels) is as many bytes as a pixel tile's activations, so one tile per workgroup pulls twice the
 // layer's bytes into the CU; two tiles halve the L2 -> LDS weight stream and the weight-fragment reads per MFMA, at 128
 // accumulator registers per lane (two workgroups per CU instead of three).
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, bool POOL, int NPT>
-__global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT>
+__global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w2,
@@ -56,48 +58,38 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
                                                        float *__restrict__ y, int64_t ybs,
                                                        const float *__restrict__ in_amax, float in_ks, float in_kb,
                                                        unsigned *__restrict__ out_amax, float y_ks, float y_kb,
-                                                       float *__restrict__ y_inv_out, int pool_w, int64_t xps,
-                                                       int64_t yps) {
+                                                       float *__restrict__ y_inv_out, int64_t xps, int64_t yps) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ float sBias[CM], sOsc[CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
-    static_assert(NPT == 1 || !POOL, "the pooling prologue runs one pixel tile per workgroup");
     constexpr int STAGE_N = 2 * PLANE_A + NPT * 2 * PLANE_B;       // bytes of one LDS stage
     const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT);
     const int co0 = blockIdx.y * CM;
     const int nk = cin / KC;
 
-    // ---- the input range -> x_scale (a power of two), identical in every lane --------------------------------
-    float x_scale, x_inv;
-    const float x_bound = fmaf(in_ks, in_amax ? range_read(in_amax) : 0.f, in_kb);
-    range_scales(x_bound, x_scale, x_inv);
+    // ---- the range of an image -> its x_scale (a power of two) ---------------------------------------------------------
     // YTERMS: the output is written already split into its two fp16 terms, scaled by 2^t with
     //     |y| <= y_ks * x_bound + y_kb      (y_ks = max_o sum_c |W[o, c]|, y_kb = max |bias|: a provable bound known BEFORE the
-    // kernel runs, unlike the true maximum) * 2^t in [2^14, 2^15); 2^-t goes to y_inv_out[0] for the consumer.
-    float y_scale = 1.f, y_inv = 1.f;
-    if (YTERMS) {
-        range_scales(fmaf(y_ks, x_bound, y_kb), y_scale, y_inv);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) y_inv_out[0] = y_inv;
-    }
+    // kernel runs, unlike the true maximum) * 2^t in [2^14, 2^15); 2^-t goes to y_inv_out[image] for the consumer.
+    auto image_bound = [&](int64_t img) { return fmaf(in_ks, in_amax ? in_amax[img] : 0.f, in_kb); };
 
     // ---- staging assignments ------------------------------------------------------------------------
     // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
     const int b_px = threadIdx.x & 127;
     const int b_kg = wave >> 1;
-    // POOL (transitions): x is the un-pooled map [.., 2 ph, 2 pw]; a staged value is the average of relu(bn(.)) over the 2 x 2
-    // input pixels of output pixel (oy, ox) -- the norm + relu + avgpool pass and its pooled tensor disappear
-    const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw; POOL: >= 4 hw)
+    const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw)
     const float *xsrc[NPT];
+    float x_scale[NPT];                                               // of this thread's pixel's image
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
+        int64_t pp = p0 + u * CP + b_px;
         int64_t b_off = 0;
-        const int64_t pp = p0 + u * CP + b_px;
-        if (pp < total) {
-            const int64_t o = pp % hw;
-            b_off = (pp / hw) * xbs + (POOL ? (2 * (o / pool_w)) * (int64_t)(2 * pool_w) + 2 * (o % pool_w) : o);
-        }
+        if (pp < total) b_off = (pp / hw) * xbs + pp % hw;
+        else pp = total - 1;                                          // a dead pixel stages image 0 with a valid scale
+        float inv_;
+        range_scales(image_bound(pp / hw), x_scale[u], inv_);
         xsrc[u] = x + b_off + (int64_t)(8 * b_kg) * in_hw;
     }
     const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + tile * 2 PLANE_B + term * PLANE_B
@@ -123,24 +115,14 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
     // TWO register sets: the activation loads of stage kt + 2 are issued while stage kt computes and stage kt + 1
     // waits in the other set.  With one set a workgroup has 8 KiB of HBM reads in flight (32 KiB per CU at four
     // workgroups): by Little's law that caps the layer near 4 TB/s, which is where the one-set kernel sat.
-    constexpr int NR = POOL ? 32 : 8;                   // raw values per thread and stage
+    constexpr int NR = 8;                               // raw values per thread and stage
     float ra[NPT][NR], rb[NPT][NR], sca[8], sha[8], scb[8], shb[8];
     auto load = [&](int kt, float (&r)[NPT][NR], float (&rsc)[8], float (&rsh)[8]) {
-        if constexpr (POOL) {
+        // (`nt` loads here, to keep the weights L2-resident, measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float *pj = xsrc[0] + ((int64_t)kt * KC + j) * in_hw;
-                const f32x2 t0 = *reinterpret_cast<const f32x2 *>(pj);
-                const f32x2 t1 = *reinterpret_cast<const f32x2 *>(pj + 2 * pool_w);
-                r[0][4 * j] = t0[0]; r[0][4 * j + 1] = t0[1]; r[0][4 * j + 2] = t1[0]; r[0][4 * j + 3] = t1[1];
-            }
-        } else {
-            // (`nt` loads here, to keep the weights L2-resident, measured 5 % SLOWER: 13.35 -> 14.0 ms per 1024 images)
+        for (int u = 0; u < NPT; ++u)
 #pragma unroll
-            for (int u = 0; u < NPT; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
-        }
+            for (int j = 0; j < 8; ++j) r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
         if (PROLOGUE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -158,23 +140,13 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x2 v;
-                if constexpr (POOL) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int c = 2 * j + e;
-                        const float s0 = fmaxf(fmaf(r[u][4 * c], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[u][4 * c + 1], rsc[c], rsh[c]), 0.f);
-                        const float s1 = fmaxf(fmaf(r[u][4 * c + 2], rsc[c], rsh[c]), 0.f) + fmaxf(fmaf(r[u][4 * c + 3], rsc[c], rsh[c]), 0.f);
-                        v[e] = (s0 + s1) * 0.25f;
-                    }
-                } else {
-                    v[0] = r[u][2 * j];
-                    v[1] = r[u][2 * j + 1];
-                    if (PROLOGUE) {
-                        v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
-                        v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
-                    }
+                v[0] = r[u][2 * j];
+                v[1] = r[u][2 * j + 1];
+                if (PROLOGUE) {
+                    v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
+                    v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
                 }
-                v = v * x_scale;
+                v = v * x_scale[u];
                 const f16x2 h = __builtin_convertvector(v, f16x2);
                 const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
                 const f16x2 l = __builtin_convertvector(r1, f16x2);
@@ -208,7 +180,7 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
 
     if (threadIdx.x < CM) {
         sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
-        sOsc[threadIdx.x] = oscale[co0 + threadIdx.x] * x_inv;
+        sOsc[threadIdx.x] = oscale[co0 + threadIdx.x];
     }
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
     auto stage = [&](int kt, int cur, float (&rnext)[NPT][NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NPT][NR],
@@ -263,7 +235,8 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 128 (ni >> 1) + 64 wn + 32 (ni & 1) + (lane & 31)
-    float vmax = 0.f;
+    // per accumulator tile column: this lane's pixel, its image and that image's scales (oscale and 2^-s are powers of two,
+    // their product is exact)
     if (YTERMS) {
         // y as the 3x3 conv wants it: [image][group g of 16 channels][term][pixel][16] fp16, where group g = 4 wm + 2 mi +
         // (lane >> 5) holds exactly the 16 channels this lane owns in accumulator tile mi (the consumer's weights are
@@ -275,6 +248,11 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
             const int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
             if (pp >= total) continue;
             const int64_t bimg = pp / hw, off = pp % hw;
+            const float xb = image_bound(bimg);
+            float xs_, x_inv, y_scale, y_inv;
+            range_scales(xb, xs_, x_inv);
+            range_scales(fmaf(y_ks, xb, y_kb), y_scale, y_inv);
+            if (off == 0 && wm == 0 && lane < 32) y_inv_out[bimg] = y_inv;     // one writer per image: the lane of its pixel 0
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int g = 4 * wm + 2 * mi + (lane >> 5);
@@ -286,7 +264,7 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * j + e;
                         const int ch = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float t = fmaf(acc[mi][ni][r], sOsc[ch], sBias[ch]);
+                        float t = fmaf(acc[mi][ni][r], sOsc[ch] * x_inv, sBias[ch]);
                         t = t < 0.f ? 0.f : t;
                         v[e] = t * y_scale;
                     }
@@ -307,22 +285,27 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
     }
 #pragma unroll
     for (int ni = 0; ni < NN; ++ni) {
-        const int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
-        if (pp >= total) continue;
+        int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
+        const bool live = pp < total;
+        if (!live) pp = total - 1;                            // carries nothing: a valid image index and vmax = 0
         const int64_t bimg = pp / hw, off = pp % hw;
+        float xs_, x_inv, vmax = 0.f;
+        range_scales(image_bound(bimg), xs_, x_inv);
         float *yo = y + bimg * ybs + off;
+        if (live) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = fmaf(acc[mi][ni][r], sOsc[ch - co0], sBias[ch - co0]);
-                if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
-                vmax = range_max(vmax, v);
-                yo[(int64_t)ch * yps] = v;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = fmaf(acc[mi][ni][r], sOsc[ch - co0] * x_inv, sBias[ch - co0]);
+                    if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
+                    vmax = range_max(vmax, v);
+                    yo[(int64_t)ch * yps] = v;
+                }
+        }
+        if (out_amax) range_publish_lanes(out_amax, (int)bimg, vmax, lane);
     }
-    if (out_amax) range_publish(out_amax, vmax, lane);
 }
 
 }  // namespace
@@ -330,37 +313,38 @@ __global__ __launch_bounds__(256, (POOL || NPT == 2) ? 2 : 3) void k_conv1x1_h2(
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, int64_t xps,
-                             int64_t yps, hipStream_t st) {
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int64_t xps, int64_t yps,
+                             hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (cin % KC || cout % CM || !oscale) return hipErrorInvalidValue;
     const bool yterms = y_inv_out != nullptr;
-    if (yterms && (cout != CM || !relu_out || !scale || pool_w)) return hipErrorInvalidValue;
-    if (pool_w && (!scale || relu_out || hw % pool_w)) return hipErrorInvalidValue;
-    if (!xps) xps = pool_w ? 4 * (int64_t)hw : hw;     // compact channel planes
+    if (yterms && (cout != CM || !relu_out || !scale)) return hipErrorInvalidValue;
+    if (!xps) xps = hw;                                // compact channel planes
     if (!yps) yps = hw;
-    if (xps < (pool_w ? 4 * (int64_t)hw : hw) || yps < hw) return hipErrorInvalidValue;
+    if (xps < hw || yps < hw) return hipErrorInvalidValue;
     // two pixel tiles per workgroup (one staged copy of the weights for both) when the launch still fills the chip
     const int64_t px = n * (int64_t)hw;
-    const int npt = (!pool_w && px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG) ? MIRX_C1H2_NPT : 1;
+    const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
     const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
-#define MIRX_H2K(P, R, T, L, N)                                                                            \
+#define MIRX_H2K(P, R, T, N)                                                                               \
     {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, L, N>),    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-        if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, L, N>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
-                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, pool_w, xps, yps); \
+        static bool attr_set = false;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
+        if (!attr_set) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + N * 2 * PLANE_B)); \
+            if (e != hipSuccess) return e;                                                                 \
+            attr_set = true;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+                           n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, xps, yps); \
     }
 #define MIRX_H2C(P, R, T)                                                                                  \
     {                                                                                                      \
-        if (npt == 2) MIRX_H2K(P, R, T, false, 2) else MIRX_H2K(P, R, T, false, 1)                          \
+        if (npt == 2) MIRX_H2K(P, R, T, 2) else MIRX_H2K(P, R, T, 1)                                        \
     }
-    if (pool_w) {
-        MIRX_H2K(true, false, false, true, 1)
-    } else if (yterms) {
+    if (yterms) {
         MIRX_H2C(true, true, true)
     } else if (scale) {
         if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)

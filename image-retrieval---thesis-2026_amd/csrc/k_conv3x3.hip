@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino(const float *__restrict
             vmax = range_max(range_max(range_max(range_max(vmax, v0.x), v0.y), v1.x), v1.y);
         }
     }
-    if (out_range) range_publish(out_range, vmax, threadIdx.x & 63);
+    (void)vmax; (void)out_range;        // range publishing lives on the two-fp16-term path only (per image, mirx_common.h)
 }
 
 // The 7x7 maps (last dense block): a map is 4 x 4 tiles (the 8th row / column of outputs is computed and
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 3) void k_conv3x3_wino7(const float *__restric
             if (col1) { o[W + 1] = v11; vmax = range_max(vmax, v11); }
         }
     }
-    if (out_range) range_publish(out_range, vmax, lane);
+    (void)vmax; (void)out_range;        // range publishing lives on the two-fp16-term path only (per image, mirx_common.h)
 }
 
 template <int W, int R>

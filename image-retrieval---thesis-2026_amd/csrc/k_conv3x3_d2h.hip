@@ -1,30 +1,24 @@
-// k_conv3x3_d2h.hip -- the direct implicit-GEMM 3x3 convolution of k_conv3x3_d3.hip (DenseNet dense layer, 128 -> 32
-// channels, stride 1, pad 1, no bias) with every fp32 operand carried as TWO fp16 terms (x = xh + xl to 22 bits) and
-// THREE v_mfma_f32_32x32x16_f16 per product block (wl xh + wh xl + wh xh; the dropped wl xl is 2^-22 of the
-// product) instead of three bf16 terms and six MFMAs: half the matrix time, 4 instead of 6 LDS bytes per element, 72
-// instead of 108 weight-fragment registers.
+// k_conv3x3_d2h.hip -- the DenseNet dense layer's 3x3 convolution (128 -> 32 channels, stride 1, pad 1, no bias) as a
+// direct implicit GEMM with every fp32 operand carried as TWO fp16 terms (x = xh + xl to 22 bits) and THREE
+// v_mfma_f32_32x32x16_f16 per product block (wl xh + wh xl + wh xh; the dropped wl xl is 2^-22 of the product).
 //
 //   D[oc, pixel] += W[oc, (tap, c)] * X[(tap, c), pixel]     K = 9 taps x 128 channels, one MFMA step = one tap x 16 c
 //
-// fp16 has 5 exponent bits, so the input's range travels with it (mirx_common.h, "value ranges"): the producing 1x1
-// conv publishes the largest value of the bottleneck map in 64 range slots; this kernel stages x * 2^s with
-// max * 2^s in [2^14, 2^15), reads weights that were scaled per OUTPUT channel by the caller (largest |w| of the
-// channel in [2^13, 2^14): mirx.model._conv3x3_weights_split2h) and multiplies the accumulator by oscale[oc] / 2^s.
-// It publishes the largest |output| it wrote into the destination buffer's range slots.
+// k_conv3x3_d2p reads the bottleneck ALREADY SPLIT into its fp16 terms by the 1x1 conv that produced it (scaled per image
+// by 2^t, 2^-t in in_inv[image]), reads weights that were scaled per OUTPUT channel by the caller (largest |w| of the channel
+// in [2^13, 2^14): mirx.model._conv3x3_weights_split2h), multiplies the accumulator by oscale[oc] * 2^-t and folds the largest
+// |output| of image b into out_range[b] (ranges are per image: mirx_common.h).
 //
-// Geometry, staging and the weight-fragment schedule are k_conv3x3_d3's:
-// one workgroup (4 waves) = a strip of R rows x W columns = 224 (196 for the 14 x 14 map) output pixels of one image
+// One workgroup (4 waves) = a strip of R rows x W columns = 224 (196 for the 14 x 14 map) output pixels of one image
 // = 7 column blocks of 32 pixels (waves 0..2 take two, wave 3 one) x all 32 output channels.
-//   * X: 16-channel stages; the padded strip ((R + 2) x (W + 2) pixels) is split into its two fp16 terms while it
-//     is staged and stored pixel-major -- [term][padded pixel][16 channels] fp16, the two 16-byte halves of a pixel
-//     at slot h ^ ((pixel >> 3) & 1) -- so the B fragment of a lane (its pixel shifted by the tap, 8 channels) is ONE
-//     ds_read_b128 per term.  Double-buffered; register-prefetched TWO stages ahead (two register sets), the split +
-//     LDS store of the next stage runs between the taps of the current one.
+//   * X: 16-channel stages of the padded strip ((R + 2) x (W + 2) pixels), pixel-major -- [term][padded pixel][16 channels]
+//     fp16, the two 16-byte halves of a pixel at slot h ^ ((pixel >> 3) & 1) -- so the B fragment of a lane (its pixel
+//     shifted by the tap, 8 channels) is ONE ds_read_b128 per term.  Double-buffered, staged by LDS DMA alone.
 //   * W: pre-split and pre-ordered by the caller ([8 stages][9 taps][2 terms][32 oc][16 c] fp16).  The 18 KiB of a
 //     stage go global -> LDS by DMA ONCE per workgroup (18 one-KiB pieces = one (tap, term) plane each, double-buffered,
-//     issued right after the stage barrier) and every wave reads its A fragments from there.  k_conv3x3_d3 lets every
-//     wave fetch its fragments from L2 itself: four times the bytes -- 144 KiB per CU per stage pair, three quarters of
-//     the L2 -> CU bandwidth, which is what bounded this kernel (0.92 ms per 1024-image 56 x 56 layer) before.
+//     issued right after the stage barrier) and every wave reads its A fragments from there.
+// (The round-2 variant with an fp32 bottleneck split inside this kernel, k_conv3x3_d2h, and the 16x16x32 re-tiling
+// k_conv3x3_d2q were A/B arms that lost to this kernel; they live in the history of this file)
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -43,242 +37,9 @@ constexpr int CIN = 128, COUT = 32;
 constexpr int KC = 16;                        // channels per stage = one MFMA K
 constexpr int NST = CIN / KC;                 // 8 stages
 
-__device__ inline void split2h(float a, float b, unsigned &h, unsigned &l) {
-    const f32x2 v = {a, b};
-    const f16x2 vh = __builtin_convertvector(v, f16x2);
-    const f32x2 r1 = v - __builtin_convertvector(vh, f32x2);
-    const f16x2 vl = __builtin_convertvector(r1, f16x2);
-    h = __builtin_bit_cast(unsigned, vh);
-    l = __builtin_bit_cast(unsigned, vl);
-}
-
-// W = map side (56 / 28 / 14); R = output rows per strip (4 / 8 / 14)
-template <int W, int R>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_d2h(const float *__restrict__ x, const uint16_t *__restrict__ w3,
-                                                        const float *__restrict__ oscale, float *__restrict__ out,
-                                                        int64_t out_bs, const float *__restrict__ in_range,
-                                                        unsigned *__restrict__ out_range) {
-    constexpr int PW = W + 2, PR = R + 2;     // padded strip
-    constexpr int NPIX = PR * PW;             // padded pixels of a stage
-    constexpr int PLANE = NPIX * 32;          // bytes of one term of one stage (32 B per pixel)
-    constexpr int STAGE = 2 * PLANE;
-    constexpr int WSTAGE = 9 * 2 * COUT * KC * 2;   // bytes of one stage of weights (18 KiB): 18 pieces of 1 KiB
-    constexpr int W_LDS0 = 2 * STAGE;               // weight buffers behind the two activation buffers
-    constexpr int NOUT = R * W;               // output pixels of a full strip
-    constexpr int NBLK = (NOUT + 31) / 32;    // 7
-    static_assert(NBLK <= 8, "two column blocks per wave");
-    extern __shared__ __attribute__((aligned(16))) char sm[];
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int half = lane >> 5, n = lane & 31;
-    const int strip = blockIdx.x;
-    const int64_t img = blockIdx.y;
-    const int oy0 = strip * R;                                // first output row of the strip
-    const float *xi = x + img * CIN * (int64_t)(W * W);
-    float x_scale, x_inv;
-    range_scales(range_read(in_range), x_scale, x_inv);
-
-    // ---- staging: item = (padded pixel, 8-channel half); thread t takes items t, t + 256, ... ----------------------
-    constexpr int NITEM = 2 * NPIX;
-    constexpr int IPT = (NITEM + 255) / 256;                  // items per thread (3 for 56 / 28, 2 for 14)
-    float rin_a[IPT][8], rin_b[IPT][8];     // two sets: stage st + 2 loads while st + 1 waits for its split + store
-    int g_off[IPT], l_off[IPT];
-    bool inside[IPT];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        int it = threadIdx.x + 256 * i;
-        const bool live = it < NITEM;
-        if (!live) it = NITEM - 1;
-        const int pix = it % NPIX, hh = it / NPIX;            // lanes walk pixels: coalesced loads per channel
-        const int pr = pix / PW, pc = pix % PW;
-        const int iy = oy0 - 1 + pr, ix = pc - 1;
-        inside[i] = live && iy >= 0 && iy < W && ix >= 0 && ix < W;
-        const int cy = iy < 0 ? 0 : (iy >= W ? W - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        g_off[i] = (8 * hh * W + cy) * W + cx;                // + (stage * 16 + j) * W * W
-        l_off[i] = live ? pix * 32 + ((hh ^ ((pix >> 3) & 1)) << 4) : -1;
-    }
-    auto load = [&](int st, float (&rin)[IPT][8]) {
-#pragma unroll
-        for (int i = 0; i < IPT; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rin[i][j] = xi[(int64_t)(st * KC + j) * (W * W) + g_off[i]];
-    };
-    // split + store of ONE staging item (8 channels of one padded pixel): called between the taps of the stage before
-    auto store_item = [&](int buf, const float (&rin)[IPT][8], int i) {
-        char *sb = sm + buf * STAGE;
-        u32x4 ph, pl;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            unsigned th, tl;
-            split2h(inside[i] ? rin[i][2 * p] * x_scale : 0.f, inside[i] ? rin[i][2 * p + 1] * x_scale : 0.f, th, tl);
-            ph[p] = th; pl[p] = tl;
-        }
-        if (l_off[i] >= 0) {
-            *reinterpret_cast<u32x4 *>(sb + l_off[i]) = ph;
-            *reinterpret_cast<u32x4 *>(sb + l_off[i] + PLANE) = pl;
-        }
-    };
-    auto store = [&](int buf, const float (&rin)[IPT][8]) {
-#pragma unroll
-        for (int i = 0; i < IPT; ++i) store_item(buf, rin, i);
-    };
-
-    // ---- this wave's column blocks and this lane's pixels --------------------------------------------------------
-    // block b covers strip pixels 32 b .. 32 b + 31 (row-major over R x W); wave w takes blocks w and w + 4
-    int pbase[2];                                             // padded index of the pixel's tap (0, 0) corner
-    bool live_blk[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int blk = wave + 4 * t;
-        live_blk[t] = blk < NBLK;                              // wave-uniform
-        int p = blk * 32 + n;
-        if (p >= NOUT) p = NOUT - 1;                           // idle lanes shadow a valid pixel (never stored)
-        pbase[t] = (p / W) * PW + (p % W);
-    }
-    // A fragments from LDS: piece (tap, term) = 32 output channels x 32 B; chunk `half` of row n sits at slot
-    // half ^ ((n >> 3) & 1) (conflict-free ds_read_b128, as in k_conv1x1_h2).  DMA: lane l of a wave writes 16 B at
-    // piece base + 16 l = (row l / 2, slot l & 1), which must hold source chunk (l & 1) ^ ((l >> 4) & 1).
-    const int a_off = n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w3, 0, NST * WSTAGE, 0x00020000);
-    const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
-    auto dma_w = [&](int st, int buf) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int piece = wave + 4 * i;               // 18 pieces: waves 0, 1 take five, waves 2, 3 four
-            if (piece < 18)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + W_LDS0 + buf * WSTAGE + piece * 1024), 16, w_voff,
-                                                         st * WSTAGE + piece * 1024, 0, 0);
-        }
-    };
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-#define MIRX_D2H_READA(DST, TAP)                                                                   \
-    {                                                                                              \
-        DST[0] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP)) * 1024 + a_off);                \
-        DST[1] = *reinterpret_cast<const f16x8 *>(wb + (2 * (TAP) + 1) * 1024 + a_off);            \
-    }
-#define MIRX_D2H_READB(DST, TAP, T)                                                                \
-    {                                                                                              \
-        const int pix_ = pbase[T] + ((TAP) / 3) * PW + (TAP) % 3;                                  \
-        const char *pb_ = sb + pix_ * 32 + ((half ^ ((pix_ >> 3) & 1)) << 4);                      \
-        DST[0] = *reinterpret_cast<const f16x8 *>(pb_);                                            \
-        DST[1] = *reinterpret_cast<const f16x8 *>(pb_ + PLANE);                                    \
-    }
-#define MIRX_D2H_MFMA(T, A, B)                                                                     \
-    {                                                                                              \
-        f32x16 c_ = acc[T];                                                                        \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], c_, 0, 0, 0);                      \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], c_, 0, 0, 0);                      \
-        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], c_, 0, 0, 0);                      \
-        acc[T] = c_;                                                                               \
-    }
-    const bool two = live_blk[1];                          // wave-uniform: waves 0..2 own two column blocks
-    // One stage.  LDS buffer `cur` holds stage st; `rstore` holds stage st + 1 (loaded one stage ago, complete since the
-    // vmcnt(0) below) and is split + stored into buffer cur ^ 1 BETWEEN the taps, in the shadow of the MFMAs -- when the
-    // split ran after the tap loop the matrix pipe idled for it (42 % busy); `rnext` receives stage st + 2.
-    auto stage = [&](int st, float (&rnext)[IPT][8], const float (&rstore)[IPT][8]) {
-        const int cur = st & 1;
-        // stage st visible: activations stored by every wave, and THIS wave's weight DMA landed (vmcnt(0): the compiler's
-        // own wait before s_barrier does not cover the asynchronous LDS writes; no counted wait -- LDS-DMA and loads to
-        // registers do not retire in one common order, see k_conv1x1_h2); buffers cur ^ 1 free
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        dma_w(st + 1 < NST ? st + 1 : st, cur ^ 1);        // branch-free: the last stages re-load the last one
-#ifndef MIRX_D2H_EXP_NOLOAD          // diagnostic build: no activation prefetch (results wrong) -> time without HBM latency
-        load(st + 2 < NST ? st + 2 : NST - 1, rnext);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        const char *sb = sm + cur * STAGE;
-        const char *wb = sm + W_LDS0 + cur * WSTAGE;
-        // fragments are read one (tap, block) unit ahead of the MFMAs that use them
-        f16x8 a0[2], a1[2], b0[2], b1[2];
-        MIRX_D2H_READA(a0, 0)
-        MIRX_D2H_READB(b0, 0, 0)
-        if (two) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                MIRX_D2H_READB(b1, tap, 1)
-                if (tap + 1 < 9) {
-                    if (tap & 1) { MIRX_D2H_READA(a0, tap + 1) } else { MIRX_D2H_READA(a1, tap + 1) }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
-                if (tap + 1 < 9) MIRX_D2H_READB(b0, tap + 1, 0)
-                if (tap % 3 == 1 && tap / 3 < IPT) store_item(cur ^ 1, rstore, tap / 3);      // taps 1, 4, 7
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap & 1) { MIRX_D2H_MFMA(1, a1, b1) } else { MIRX_D2H_MFMA(1, a0, b1) }
-            }
-        } else {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap + 1 < 9) {
-                    MIRX_D2H_READB(b1, tap + 1, 0)
-                    if (tap & 1) { MIRX_D2H_READA(a0, tap + 1) } else { MIRX_D2H_READA(a1, tap + 1) }
-                }
-                if (tap % 3 == 1 && tap / 3 < IPT) store_item(cur ^ 1, rstore, tap / 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap & 1) { MIRX_D2H_MFMA(0, a1, b0) } else { MIRX_D2H_MFMA(0, a0, b0) }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) b0[q] = b1[q];
-            }
-        }
-    };
-    dma_w(0, 0);
-    load(0, rin_a);
-    load(1, rin_b);
-    store(0, rin_a);
-    static_assert(NST % 2 == 0, "the stage loop runs in pairs");
-    for (int st = 0; st < NST; st += 2) {
-        stage(st, rin_a, rin_b);                           // fetch st + 2 into a, publish b = st + 1
-        stage(st + 1, rin_b, rin_a);
-    }
-#undef MIRX_D2H_READA
-#undef MIRX_D2H_READB
-#undef MIRX_D2H_MFMA
-
-    // ---- outputs straight from the accumulators: register r = channel 8 (r >> 2) + (r & 3) + 4 half, lane = pixel ----
-    float *oi = out + img * out_bs + (int64_t)oy0 * W;
-    float osc[16], vmax = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int p = (wave + 4 * t) * 32 + n;
-        if (live_blk[t] && p < NOUT && oy0 + p / W < W) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
-                const float v = acc[t][r] * osc[r];
-                vmax = range_max(vmax, v);
-                oi[(int64_t)oc * (W * W) + p] = v;
-            }
-        }
-    }
-    if (out_range) range_publish(out_range, vmax, lane);
-}
-
-template <int W, int R>
-hipError_t launch_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
-                      const float *in_range, float *out_range, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * (R + 2) * (W + 2) * 32 + 2 * 9 * 2 * 32 * 16 * 2;     // activations + weights, both double-buffered
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2h<W, R>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_conv3x3_d2h<W, R>), dim3((W + R - 1) / R, (unsigned)n), dim3(256), lds, st, x, w2, oscale, out,
-                       out_bs, in_range, reinterpret_cast<unsigned *>(out_range));
-    return hipGetLastError();
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// k_conv3x3_d2p: the same convolution reading the bottleneck ALREADY SPLIT into its two fp16 terms by the 1x1 conv that
-// produced it (k_conv1x1_h2<.., YTERMS>): yt = [image][group of 16 channels][term][pixel][16] fp16, scaled by 2^t, 2^-t in
-// in_inv[0].  Staging is then pure LDS DMA -- no register prefetch, no split, no LDS stores: piece j of a term plane =
+// k_conv3x3_d2p: yt = [image][group of 16 channels][term][pixel][16] fp16 (k_conv1x1_h2<.., YTERMS>), scaled by 2^t, 2^-t in
+// in_inv[image].  Staging is then pure LDS DMA -- no register prefetch, no split, no LDS stores: piece j of a term plane =
 // padded pixels 32 j .. 32 j + 31 (lane l -> pixel 32 j + l / 2, 16-byte slot l & 1, which must hold channel chunk
 // (l & 1) ^ ((pixel >> 3) & 1)); a lane's source offset is its pixel's position inside the image, or an offset beyond the
 // buffer's num_records for the padding ring (out-of-range buffer loads return zero: the halo needs no branch and no
@@ -461,27 +222,33 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const 
 #undef MIRX_D2P_MFMA
 
     // ---- outputs straight from the accumulators: register r = channel 8 (r >> 2) + (r & 3) + 4 half, lane = pixel ----
-    const float x_inv = in_inv[0];
     float *oi = out + img * out_bs + (int64_t)oy0 * W;        // IPW > 1: image j of the workgroup at + j * out_bs
-    float osc[16], vmax = 0.f;
+    float osc[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half] * x_inv;
+    for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int p = (wave + NW * t) * 32 + n;
         const int pj = p / (R * W), pq = p % (R * W);
-        if (live_blk[t] && p < NOUT && pj < n_here && oy0 + pq / W < W) {
+        const bool live = live_blk[t] && p < NOUT && pj < n_here && oy0 + pq / W < W;
+        const int pimg = (int)img + (pj < n_here ? pj : 0);            // a lane that carries nothing: a valid image, vmax = 0
+        float vmax = 0.f;
+        if (live) {
+            const float x_inv = in_inv[pimg];                          // 2^-t of this pixel's image (oscale * 2^-t is exact)
             float *op = oi + (int64_t)pj * out_bs + pq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int oc = 8 * (r >> 2) + (r & 3) + 4 * half;
-                const float v = acc[t][r] * osc[r];
+                const float v = acc[t][r] * (osc[r] * x_inv);
                 vmax = range_max(vmax, v);
                 op[(int64_t)oc * out_ps] = v;
             }
         }
+        if (out_range && live_blk[t]) {                                // wave-uniform
+            if (IPW == 1) range_publish(out_range, (int)img, vmax, lane);
+            else range_publish_lanes(out_range, pimg, vmax, lane);
+        }
     }
-    if (out_range) range_publish(out_range, vmax, lane);
 }
 
 template <int W, int R, int IPW = 1, int NW = 4>
@@ -490,25 +257,19 @@ hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscal
     constexpr int NP = (IPW * (R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
     static_assert((size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2 <= 160 * 1024, "LDS of one CU");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW, NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static bool attr_set = false;          // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW, NW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(64 * NW), lds,
                        st, yt, w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);
     return hipGetLastError();
 }
 
 }  // namespace
-
-hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_range, float *out_range, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    if (n > 65535 || !in_range || !oscale) return hipErrorInvalidValue;
-    if (side == 56) return launch_d2h<56, 4>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
-    if (side == 28) return launch_d2h<28, 8>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
-    if (side == 14) return launch_d2h<14, 14>(x, w2, oscale, n, out, out_bs, in_range, out_range, st);
-    return hipErrorInvalidValue;
-}
 
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {

@@ -125,21 +125,6 @@ __global__ __launch_bounds__(256) void k_grn_norm(const float *__restrict__ x, i
     if (wave == 0 && c0 < c) gx[img * c + c0] = sqrtf((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
-__global__ __launch_bounds__(256) void k_grn_apply(float *__restrict__ x, int64_t total4, int hw, int c4,
-                                                   const float *__restrict__ scale, const float *__restrict__ shift) {
-    typedef __attribute__((ext_vector_type(4))) float f32x4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int cc = (int)(i % c4);
-        const int64_t img = i / ((int64_t)hw * c4);
-        f32x4 v = reinterpret_cast<f32x4 *>(x)[i];
-        const f32x4 sc = reinterpret_cast<const f32x4 *>(scale)[img * c4 + cc];
-        const f32x4 sh = reinterpret_cast<const f32x4 *>(shift)[cc];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
-        reinterpret_cast<f32x4 *>(x)[i] = v;
-    }
-}
-
 // GRN scale vector: scale[b, c] = 1 + weight[c] * gx[b, c] / (mean_c gx[b, :] + eps), and the largest |scale| of the whole
 // batch into smax[0] (the two-fp16-term Linear that folds the scale into its staging reads it as its device-side bound):
 // unsigned atomic max on the float's bits (|scale| >= 0; NaN / inf sort above everything), smax zeroed by the caller.
@@ -203,16 +188,6 @@ hipError_t launch_grn_norm(const float *x, int64_t n, int hw, int c, float *gx, 
     if (n <= 0) return hipSuccess;
     if (n > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_grn_norm, dim3((unsigned)((c + 63) / 64), (unsigned)n), dim3(256), 0, st, x, hw, c, gx);
-    return hipGetLastError();
-}
-
-hipError_t launch_grn_apply(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    if (c % 4) return hipErrorInvalidValue;
-    const int64_t total4 = n * hw * (int64_t)(c / 4);
-    const int64_t blocks = (total4 + 255) / 256;
-    hipLaunchKernelGGL(k_grn_apply, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, x, total4, hw,
-                       c / 4, scale, shift);
     return hipGetLastError();
 }
 

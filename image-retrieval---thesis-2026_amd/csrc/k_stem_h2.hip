@@ -3,11 +3,11 @@
 // v_mfma_f32_32x32x16_f16 per product block: wl xh + wh xl + wh xh, the dropped wl xl is 2^-22 of the product) instead
 // of three bf16 terms and six MFMAs: 66 MFMAs of 32 cycles per wave instead of 132.
 //
-// fp16 needs the range of the input: `in_range` = 64 range slots holding the largest |pixel| of the image batch
-// (mirx_range_absmax, one pass over the images); the patch is multiplied by 2^s (bound * 2^s in [2^14, 2^15)) while it is
+// fp16 needs the range of the input: `in_range[b]` = the largest |pixel| of image b (mirx_range_absmax, one pass over
+// the images; ranges are per image, mirx_common.h); the patch is multiplied by 2^s (bound * 2^s in [2^14, 2^15)) while it is
 // staged, the weights arrive scaled per output channel (mirx.model._stem_weights_split2h) and the accumulator is
 // multiplied by oscale[oc] / 2^s before norm0.  Tiling, patch layout and pooling are k_stem_s3's; it writes image b at
-// y + b * y_bs (the channel prefix of dense block 1's buffer) and publishes the largest pooled value in `out_range`.
+// y + b * y_bs (the channel prefix of dense block 1's buffer) and folds the largest pooled value into `out_range[b]`.
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input row/col of the patch
     const float *xi = x + img * 3 * (int64_t)h * wd;
     float x_scale, x_inv;
-    range_scales(range_read(in_range), x_scale, x_inv);
+    range_scales(in_range[img], x_scale, x_inv);
     // per-channel epilogue constants (accumulator scale, norm0 scale and shift) once per workgroup: the epilogue reads them
     // from LDS instead of three cached global loads per accumulator register
     float *s_par = sm + PAR_OFF / 4;     // [64][4]: oscale * 2^-s, scale, shift
@@ -251,11 +251,12 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, cbase[dy * CTW + dx]);
+            if (x_inv != x_inv) m = x_inv;               // a non-finite input range: NaN out (relu and max above drop NaNs)
             yi[((int64_t)oc * ph + py) * pw + px] = m;
             vmax = range_max(vmax, m);
         }
     }
-    if (out_range) range_publish(out_range, vmax, threadIdx.x & 63);
+    if (out_range) range_publish(out_range, (int)img, vmax, threadIdx.x & 63);
 }
 
 }  // namespace
@@ -276,24 +277,32 @@ hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscal
     return hipGetLastError();
 }
 
-// ---- largest |value| of a flat fp32 array into range slots (the input images of the two-fp16-term stem) ----------
+// ---- largest |value| of every image (`per` contiguous fp32 each) into its range: grid (chunks, images) -----------------
 namespace {
-__global__ __launch_bounds__(256) void k_range_absmax(const float *__restrict__ x, int64_t n, unsigned *__restrict__ slots) {
+__global__ __launch_bounds__(256) void k_range_absmax(const float *__restrict__ x, int64_t per, unsigned *__restrict__ row) {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const float *xi = x + (int64_t)blockIdx.y * per;
     float m = 0.f;
-    const int64_t nv = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
-        m = range_max(range_max(range_max(range_max(m, v[0]), v[1]), v[2]), v[3]);
+    if ((reinterpret_cast<uintptr_t>(xi) & 15) == 0) {
+        const int64_t nv = per >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(xi)[i];
+            m = range_max(range_max(range_max(range_max(m, v[0]), v[1]), v[2]), v[3]);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (per & 3)) m = range_max(m, xi[(nv << 2) + threadIdx.x]);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) m = range_max(m, xi[i]);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = range_max(m, x[(nv << 2) + threadIdx.x]);
-    range_publish(slots, m, threadIdx.x & 63);
+    range_publish(row, (int)blockIdx.y, m, threadIdx.x & 63);
 }
 }  // namespace
 
-hipError_t launch_range_absmax(const float *x, int64_t n, float *slots, hipStream_t st) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_range_absmax, dim3(2048), dim3(256), 0, st, x, n, reinterpret_cast<unsigned *>(slots));
+hipError_t launch_range_absmax(const float *x, int64_t per, int64_t n, float *row, hipStream_t st) {
+    if (n <= 0 || per <= 0) return hipSuccess;
+    if (n > 65535) return hipErrorInvalidValue;
+    const int64_t want = (per / 4 + 255) / 256;                 // one 16-byte load per thread
+    const unsigned chunks = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    hipLaunchKernelGGL(k_range_absmax, dim3(chunks, (unsigned)n), dim3(256), 0, st, x, per, reinterpret_cast<unsigned *>(row));
     return hipGetLastError();
 }
 

@@ -735,26 +735,11 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                "conv1x1_split2h: in_ks / in_kb are non-negative; without range slots in_kb is the bound itself");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1_or_null, shift1_or_null,
                                reinterpret_cast<const uint16_t *>(w2), oscale, bias_or_null, n, hw, cout, relu_out, y,
-                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr, 0,
+                               y_batch_stride, in_range_or_null, in_ks, in_kb, out_range_or_null, 0.f, 0.f, nullptr,
                                x_plane_stride, y_plane_stride, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
-int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale,
-                                                 const float *shift, const void *w2, const float *oscale, int64_t n, int h,
-                                                 int w, int cout, float *y, int64_t y_batch_stride, const float *in_range,
-                                                 float in_ks, float in_kb, float *out_range_or_null, void *stream) {
-    MIRX_CHECK(n >= 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "transition: H and W must be even");
-    MIRX_CHECK(cin >= 16 && cin % 16 == 0 && cout >= 128 && cout % 128 == 0, "transition: cin % 16 == 0, cout % 128 == 0");
-    MIRX_CHECK(n == 0 || (x && scale && shift && w2 && oscale && y && in_range), "transition: null buffer");
-    MIRX_CHECK(x_batch_stride >= (int64_t)cin * h * w && y_batch_stride >= (int64_t)cout * (h / 2) * (w / 2),
-               "transition: batch stride too small");
-    MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f, "transition: bounds are non-negative");
-    MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale, shift, reinterpret_cast<const uint16_t *>(w2), oscale, nullptr, n,
-                               (h / 2) * (w / 2), cout, 0, y, y_batch_stride, in_range, in_ks, in_kb, out_range_or_null, 0.f,
-                               0.f, nullptr, w / 2, 0, 0, reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
 
 int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
                                        const float *shift1, const void *w2, const float *oscale, const float *bias,
@@ -769,46 +754,23 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
     MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && y_ks >= 0.f && y_kb >= 0.f, "conv1x1_split2h_terms: bounds are non-negative");
     MIRX_HIP(launch_conv1x1_h2(x, x_batch_stride, cin, scale1, shift1, reinterpret_cast<const uint16_t *>(w2), oscale, bias, n,
                                hw, 128, 1, reinterpret_cast<float *>(y_terms), 0, in_range, in_ks, in_kb, nullptr, y_ks, y_kb,
-                               y_inv_out, 0, x_plane_stride, 0, reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
-
-static int conv3x3_terms_impl(bool mfma16, const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
-                              float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
-                              int64_t out_plane_stride, void *stream) {
-    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
-    MIRX_CHECK(side == 56 || side == 28 || side == 14 || (side == 7 && !mfma16),
-               "conv3x3_terms: side must be 56, 28, 14 or 7 (mfma16 arm: 56, 28, 14)");
-    MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
-    if (!out_plane_stride) out_plane_stride = (int64_t)side * side;
-    MIRX_CHECK(out_plane_stride >= (int64_t)side * side, "conv3x3_terms: the plane stride is 0 (= side^2) or at least side^2");
-    MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms: output batch stride too small");
-    MIRX_CHECK(!mfma16 || ((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0 && out_plane_stride % 4 == 0),
-               "conv3x3_terms (mfma16 arm, 16-byte stores): out 16-byte aligned, batch and plane strides multiples of 4 floats");
-    if (mfma16) {
-        MIRX_HIP(launch_conv3x3_d2q(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                    side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
-                                    reinterpret_cast<hipStream_t>(stream)));
-    } else {
-        MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
-                                    side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
-                                    reinterpret_cast<hipStream_t>(stream)));
-    }
+                               y_inv_out, x_plane_stride, 0, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
                                    int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                                    int64_t out_plane_stride, void *stream) {
-    return conv3x3_terms_impl(false, y_terms, w2, oscale, n, side, out, out_batch_stride, y_inv, out_range_or_null,
-                              out_plane_stride, stream);
-}
-
-int mirx_conv3x3_direct_terms_nchw_mfma16(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
-                                          float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
-                                          int64_t out_plane_stride, void *stream) {
-    return conv3x3_terms_impl(true, y_terms, w2, oscale, n, side, out, out_batch_stride, y_inv, out_range_or_null,
-                              out_plane_stride, stream);
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14 || side == 7, "conv3x3_terms: side must be 56, 28, 14 or 7");
+    MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv), "conv3x3_terms: null buffer");
+    if (!out_plane_stride) out_plane_stride = (int64_t)side * side;
+    MIRX_CHECK(out_plane_stride >= (int64_t)side * side, "conv3x3_terms: the plane stride is 0 (= side^2) or at least side^2");
+    MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms: output batch stride too small");
+    MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
 }
 
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
@@ -892,12 +854,6 @@ int mirx_grn_scale(const float *gx, const float *weight, int64_t n, int c, float
     return MIRX_OK;
 }
 
-int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream) {
-    MIRX_CHECK(n >= 0 && hw >= 1 && c >= 4 && c % 4 == 0 && (n == 0 || (x && scale && shift)),
-               "grn_apply: c must be a multiple of 4");
-    MIRX_HIP(launch_grn_apply(x, n, hw, c, scale, shift, reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
 
 int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
                    float *y, int tokens_per_image, void *stream) {
@@ -947,28 +903,7 @@ int mirx_conv3x3_winograd_nchw(const float *x, const float *u, int64_t n, int si
     return MIRX_OK;
 }
 
-int mirx_conv3x3_winograd_nchw_ranged(const float *x, const float *u, int64_t n, int side, float *out,
-                                      int64_t out_batch_stride, float *out_range_or_null, void *stream) {
-    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3: batch must be in [0, 65535]");
-    MIRX_CHECK(side == 56 || side == 28 || side == 14 || side == 7, "conv3x3: side must be 56, 28, 14 or 7");
-    MIRX_CHECK(n == 0 || (x && u && out), "conv3x3: null buffer");
-    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3: output batch stride too small");
-    MIRX_HIP(launch_conv3x3_wino(x, u, n, side, out, out_batch_stride, out_range_or_null,
-                                 reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
 
-int mirx_conv3x3_direct_split2h_nchw(const float *x, const void *w2, const float *oscale, int64_t n, int side, float *out,
-                                     int64_t out_batch_stride, const float *in_range, float *out_range_or_null,
-                                     void *stream) {
-    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_split2h: batch must be in [0, 65535]");
-    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_split2h: side must be 56, 28 or 14");
-    MIRX_CHECK(n == 0 || (x && w2 && oscale && out && in_range), "conv3x3_split2h: null buffer");
-    MIRX_CHECK(out_batch_stride >= (int64_t)32 * side * side, "conv3x3_split2h: output batch stride too small");
-    MIRX_HIP(launch_conv3x3_d2h(x, reinterpret_cast<const uint16_t *>(w2), oscale, n, side, out, out_batch_stride, in_range,
-                                out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
 
 int mirx_conv3x3_winograd_split3_nchw(const float *x, const void *u3, int64_t n, int side, float *out,
                                       int64_t out_batch_stride, void *stream) {
@@ -1105,10 +1040,10 @@ int mirx_stem_conv7_bn_relu_pool_split3(const float *x, const void *w3, const fl
     return MIRX_OK;
 }
 
-int mirx_range_absmax(const float *x, int64_t n, float *range_slots, void *stream) {
-    MIRX_CHECK(n >= 0 && (n == 0 || (x && range_slots)), "range_absmax: null buffer");
-    MIRX_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0, "range_absmax: x must be 16-byte aligned");
-    MIRX_HIP(launch_range_absmax(x, n, range_slots, reinterpret_cast<hipStream_t>(stream)));
+int mirx_range_absmax(const float *x, int64_t per_image, int64_t n, float *range_row, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && per_image >= 0, "range_absmax: batch must be in [0, 65535]");
+    MIRX_CHECK(n == 0 || per_image == 0 || (x && range_row), "range_absmax: null buffer");
+    MIRX_HIP(launch_range_absmax(x, per_image, n, range_row, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 
@@ -1124,16 +1059,6 @@ int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, co
     return MIRX_OK;
 }
 
-int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
-                                             int64_t n, int h, int wd, float *y, int64_t y_batch_stride,
-                                             float *out_range_or_null, void *stream) {
-    MIRX_CHECK(x && w3 && scale && shift && y && n >= 0 && n <= 65535, "stem_split3: null argument or batch > 65535");
-    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split3: H and W must be multiples of 4");
-    MIRX_CHECK(y_batch_stride >= (int64_t)64 * (h / 4) * (wd / 4), "stem_split3: output batch stride too small");
-    MIRX_HIP(launch_stem_s3(x, reinterpret_cast<const uint16_t *>(w3), scale, shift, n, h, wd, y, y_batch_stride,
-                            out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
-    return MIRX_OK;
-}
 
 int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const float *scale, const float *shift,
                          const float *wt, const float *bias, int64_t n, int hw, int cout, int relu_out, float *y,

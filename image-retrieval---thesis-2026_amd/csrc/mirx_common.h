@@ -100,29 +100,39 @@ __device__ inline float gelu_tanh(float v) {
 }
 
 // ---- value ranges that travel with activations (two-fp16-term kernels) ---------------------------------
-// A producer publishes the largest |value| it wrote into one of RANGE_SLOTS floats (slot = workgroup % 64) with an
-// unsigned atomic max: the bit patterns of non-negative floats order like the floats, +inf and NaN sort above every
-// finite value, so a non-finite output makes the consumer's scale NaN and its whole output NaN (loud, never a silently
-// wrong finite number).  A consumer reduces the 64 slots and derives its power-of-two staging scale.
-constexpr int RANGE_SLOTS = 64;
-
-__device__ inline float range_shfl_xor(float v, int off) { return __shfl_xor(v, off, 64); }
-
+// PER IMAGE: a buffer's range is one fp32 per image (a "range row" [n], zeroed once per forward).  A producer folds the
+// largest |value| it wrote for image b into row[b] with an unsigned atomic max: the bit patterns of non-negative floats
+// order like the floats, +inf and NaN sort above every finite value, so a non-finite activation makes THAT image's
+// consumer scale NaN and its embedding NaN (loud, never a silently wrong finite number) and leaves its batch mates
+// untouched.  A consumer reads row[b] and derives the power-of-two staging scale of image b: an image's arithmetic does
+// not depend on what else is in the batch.
 __device__ inline float range_max(float m, float v) {
     // max(m, |v|) that keeps a NaN (fmaxf would drop it)
     const float a = fabsf(v);
     return (a > m || a != a) ? a : m;
 }
 
-// the maximum of the 64 slots, the same value in every lane (one wave-wide load)
-__device__ inline float range_read(const float *__restrict__ slots) {
-    unsigned a = __float_as_uint(slots[threadIdx.x & 63]);
+// every lane of the wave belongs to image `img` (wave-uniform): one atomic per wave
+__device__ inline void range_publish(unsigned *__restrict__ row, int img, float vmax, int lane) {
+    unsigned a = __float_as_uint(vmax);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)a, off, 64);
         a = o > a ? o : a;
     }
-    return __uint_as_float(a);
+    if (lane == 0 && a) atomicMax(row + img, a);
+}
+
+// lanes may belong to different images (a pixel tile that straddles images; a lane that carries nothing passes a valid
+// image index and vmax = 0): one atomic per wave where the wave is uniform, one per lane otherwise
+__device__ inline void range_publish_lanes(unsigned *__restrict__ row, int img, float vmax, int lane) {
+    const int first = __builtin_amdgcn_readfirstlane(img);
+    if (__all(img == first)) {                     // wave-uniform branch
+        range_publish(row, first, vmax, lane);
+    } else {
+        const unsigned a = __float_as_uint(vmax);
+        if (a) atomicMax(row + img, a);
+    }
 }
 
 // bound >= every |value|: x_scale = 2^(14 - floor(log2 bound)) puts bound * x_scale in [2^14, 2^15) (fp16 overflows at
@@ -140,15 +150,6 @@ __device__ inline void range_scales(float bound, float &x_scale, float &inv) {
     }
 }
 
-__device__ inline void range_publish(unsigned *__restrict__ slots, float vmax, int lane) {
-    unsigned a = __float_as_uint(vmax);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned o = (unsigned)__shfl_xor((int)a, off, 64);
-        a = o > a ? o : a;
-    }
-    if (lane == 0 && a) atomicMax(slots + (blockIdx.x & (RANGE_SLOTS - 1)), a);
-}
 #endif  // __HIPCC__
 
 }  // namespace mirx

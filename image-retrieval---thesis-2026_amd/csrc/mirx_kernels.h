@@ -35,7 +35,7 @@ hipError_t launch_stem_s3(const float *x, const uint16_t *w3, const float *scale
 hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscale, const float *scale, const float *shift,
                           int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
                           hipStream_t st);
-hipError_t launch_range_absmax(const float *x, int64_t n, float *slots, hipStream_t st);
+hipError_t launch_range_absmax(const float *x, int64_t per_image, int64_t n, float *row, hipStream_t st);
 
 // ---- k_conv1x1.hip ----------------------------------------------------------------------
 hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
@@ -50,7 +50,6 @@ hipError_t launch_grn_norm(const float *x, int64_t n, int hw, int c, float *gx, 
 hipError_t launch_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *smax,
                             hipStream_t st);
 // x[b][p][c] = x[b][p][c] * scale[b][c] + shift[c], in place
-hipError_t launch_grn_apply(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, hipStream_t st);
 
 // ---- k_exact.hip ------------------------------------------------------------------------
 // out[i*ld + j] = fp64 ranking score of query qlist[i] (or i when qlist == null) vs row j.
@@ -80,8 +79,8 @@ hipError_t launch_conv1x1_s3(const float *x, int64_t xbs, int cin, const float *
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
-                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int pool_w, int64_t xps,
-                             int64_t yps, hipStream_t st);
+                             float *out_amax, float y_ks, float y_kb, float *y_inv_out, int64_t xps, int64_t yps,
+                             hipStream_t st);
 
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
@@ -106,8 +105,6 @@ hipError_t launch_conv3x3_d3(const float *x, const uint16_t *w3, int64_t n, int 
 
 // ---- k_conv3x3_d2h.hip: the direct implicit GEMM on two fp16 terms per operand; ranges travel in range slots ------
 // w2 = [8 stages][9 taps][2 terms][32 oc][16 c] fp16 (scaled per output channel), oscale = [32] fp32
-hipError_t launch_conv3x3_d2h(const float *x, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_range, float *out_range, hipStream_t st);
 
 // ---- k_norm.hip: LayerNorm over rows, patchify (+ LayerNorm2d), attention for short query sets ------------------
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
@@ -120,9 +117,6 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
 
 // k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
-// k_conv3x3_d2q.hip: the same on v_mfma_f32_16x16x32_f16 (A/B arm: mirx_conv3x3_direct_terms_nchw_mfma16; `out` 16-byte aligned)
-hipError_t launch_conv3x3_d2q(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
 
 // ---- k_attention.hip --------------------------------------------------------------------

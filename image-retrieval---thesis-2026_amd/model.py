@@ -216,83 +216,51 @@ def _plane_stride(side):
     (tools/bench_embed.py --plane-stride 14:224)."""
     hw = side * side
     ps = PLANE_STRIDE_H2.get(side, hw)
-    if CONV3X3_KERNEL_H2.get(side, "wino") != "terms":
-        return hw
     assert ps == hw or (ps > hw and ps % 4 == 0)
     return ps
 
 
 def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None):
     """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, plane stride] (side x side pixels per plane, see
-    _plane_stride) already holds the first block.cin channels and `brange` (64 range slots) bounds them.  Every layer on
-    the 56 / 28 / 14 maps: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT
-    into fp16 terms, scaled by a bound it derives from brange before it runs (2^-t goes to the layer's row of `lranges`);
-    conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange (7 x 7 maps: four
-    images per workgroup).  CONV3X3_KERNEL_H2 "direct2h" / "wino": fp32 bottleneck + in-kernel split / fp32 Winograd."""
+    _plane_stride) already holds the first block.cin channels and `brange` (range row [B]: one float per image) bounds them.
+    Every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT into fp16
+    terms, image b scaled by a bound derived from brange[b] before the kernel runs (2^-t goes to the layer's row of
+    `lranges`); conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange
+    (7 x 7 maps: four images per workgroup)."""
     lib = _lib.load()
     b, _, ps = buf.shape
     h = w = side
     st = _stream(buf.device)
     c = block.cin
-    terms = CONV3X3_KERNEL_H2.get(h, "wino") == "terms"
-    assert terms or ps == h * w                                   # only the terms kernels take a plane stride
-    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)      # fp32 map, or the same bytes as terms
+    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)      # the bytes of an fp32 map, as terms
     for li, name in enumerate(block.keys()):
         e = cache[name]
         dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * ps)
         ev = _timer_start(timer)
-        if terms:
-            _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * ps, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
-                                                              _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, _ptr(y),
-                                                              _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
-                                                              _ptr(lranges[li]), ps, st), "mirx_conv1x1_bn_relu_split2h_terms")
-            _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
-            _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
-                                                          block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
-                       "mirx_conv3x3_direct_terms_nchw")
-            c += GROWTH
-            continue
-        _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(buf), block.cout * h * w, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
-                                                    _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, y.shape[1], 1,
-                                                    _ptr(y), y.shape[1] * h * w, _ptr(brange), e["ks"], e["kb"],
-                                                    _ptr(lranges[li]), 0, 0, st), "mirx_conv1x1_bn_relu_split2h")
+        _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * ps, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
+                                                          _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, _ptr(y),
+                                                          _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
+                                                          _ptr(lranges[li]), ps, st), "mirx_conv1x1_bn_relu_split2h_terms")
         _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
-        if CONV3X3_KERNEL_H2.get(h, "wino") == "direct2h":
-            _lib.check(lib.mirx_conv3x3_direct_split2h_nchw(_ptr(y), _ptr(e["c3w2"]), _ptr(e["c3osc"]), b, h, dst,
-                                                            block.cout * h * w, _ptr(lranges[li]), _ptr(brange), st),
-                       "mirx_conv3x3_direct_split2h_nchw")
-        else:
-            _lib.check(lib.mirx_conv3x3_winograd_nchw_ranged(_ptr(y), _ptr(e["u"]), b, h, dst, block.cout * h * w,
-                                                             _ptr(brange), st), "mirx_conv3x3_winograd_nchw_ranged")
+        _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
+                                                      block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
+                   "mirx_conv3x3_direct_terms_nchw")
         c += GROWTH
     return buf
-
-
-# transitions: norm + relu + avgpool inside the 1x1 conv's staging (one launch).  Measured equal within noise (43.0 vs 43.2 k
-# img/s at B = 4096): each of the cout / 128 channel tiles re-reads the un-pooled map, which costs what the saved pass cost.
-# (Packed planes only.)
-FUSED_TRANSITION_POOL = False
 
 
 def _transition_h2(buf, side, cache, brange, next_buf, next_range, timer=None):
     """norm -> relu -> avgpool2 -> conv 1x1 (the pool commutes with the linear conv; two fp16 terms; the pooled values are
     averages of relu(bn(x)), so max|scale| * range + max|shift| bounds them) written into the channel prefix of the next
-    block's buffer [B, C', its plane stride], whose range slots receive the output range.  FUSED_TRANSITION_POOL: one launch,
-    the pool runs in the conv's staging; otherwise a bn + relu + avgpool pass feeds the plain 1x1 conv."""
+    block's buffer [B, C', its plane stride], whose range row receives the output ranges: a bn + relu + avgpool pass feeds
+    the plain 1x1 conv.  (A one-launch form with the pool inside the conv's staging measured equal in round 2 -- every
+    128-channel output tile re-reads the un-pooled map -- and was dropped.)"""
     lib = _lib.load()
     b, c, ps = buf.shape
     h = w = side
     st = _stream(buf.device)
     hw2 = (h // 2) * (w // 2)
     nps = next_buf.shape[2]
-    if FUSED_TRANSITION_POOL and ps == h * w and nps == hw2:
-        ev = _timer_start(timer)
-        _lib.check(lib.mirx_transition_bn_relu_pool_conv1x1_split2h(
-            _ptr(buf), c * h * w, c, _ptr(cache["sc"]), _ptr(cache["sh"]), _ptr(cache["w2"]), _ptr(cache["osc"]), b, h, w,
-            c // 2, _ptr(next_buf), next_buf.shape[1] * hw2, _ptr(brange), cache["ks"], cache["kb"], _ptr(next_range), st),
-            "mirx_transition_bn_relu_pool_conv1x1_split2h")
-        _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2))
-        return next_buf
     pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
     _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * ps, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled), ps,
                                          st), "mirx_bn_relu_avgpool2")
@@ -486,10 +454,9 @@ def _stream(dev):
 
 
 CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
-# Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations in "range slots" (include/mirx.h,
-# mirx_conv1x1_bn_relu_split2h); kernels per map side must publish ranges: "terms", "direct2h" or "wino" (fp32 Winograd).
+# Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations, one float per image and buffer
+# (include/mirx.h, mirx_conv1x1_bn_relu_split2h)
 SPLIT2H_DENSENET = True
-CONV3X3_KERNEL_H2 = {56: "terms", 28: "terms", 14: "terms", 7: "terms"}      # "terms": pre-split bottleneck (see _dense_block_h2)
 SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
 SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
@@ -538,10 +505,16 @@ def _linear_h2_weights(mod):
     return cached[1], cached[2]
 
 
+def _tkey(t):
+    """Cache key of a parameter: a replaced tensor object (load_state_dict(assign=True), `m.weight = nn.Parameter(..)`,
+    `p.data = ..`) starts again at version 0, so the version alone would keep a stale entry alive."""
+    return None if t is None else (id(t), t.data_ptr(), t._version)
+
+
 def _layernorm_bound(ln):
     """max |LayerNorm(x)_j| over all inputs: |x_j - mean| / std <= sqrt(C - 1), so sqrt(C - 1) max|gamma| + max|beta|."""
     g, b = ln.weight, ln.bias
-    key = (None if g is None else g._version, None if b is None else b._version)
+    key = (_tkey(g), _tkey(b))
     cached = getattr(ln, "_mirx_bound", None)
     if cached is None or cached[0] != key:
         c = ln.normalized_shape[-1]
@@ -557,8 +530,7 @@ def _linear_out_bound(ln, lin, rows=None):
     ||LN(x)||_2 <= max|gamma| sqrt(C) + ||beta||_2 (the normalised vector has squared norm C), so
     |y_j| <= that * ||W_j||_2 + |b_j|.  GELU and softmax-weighted averages of such outputs obey the same bound."""
     g, b = ln.weight, ln.bias
-    ver = (None if g is None else g._version, None if b is None else b._version, lin.weight._version, lin.weight.data_ptr(),
-           None if lin.bias is None else lin.bias._version)
+    ver = (_tkey(g), _tkey(b), _tkey(lin.weight), _tkey(lin.bias))
     store = lin.__dict__.setdefault("_mirx_out_bound", {})
     if store.get("ver") != ver:                      # weights changed: every cached row range is stale
         store.clear()
@@ -757,17 +729,32 @@ class DenseNet121(nn.Module):
     # any of those changed: tensor versions are summed on every forward (in-place edits, load_state_dict through a
     # parent module and copy_ all bump them), device moves and dtype casts arrive through _apply.
     def _weights_version(self):
+        """(sum of tensor versions, sum of tensor identities) over every parameter and BatchNorm buffer of the feature
+        stack, read through the owning modules' dicts on every forward: in-place edits bump the first, a REPLACED tensor
+        object (load_state_dict(assign=True), `conv.weight = nn.Parameter(..)`) changes the second."""
         watch = self.__dict__.get("_mirx_watch")
         if watch is None:
-            f = self.densenet121[0]
-            watch = list(f.parameters()) + list(f.buffers())
+            watch = []
+            for m in self.densenet121[0].modules():
+                watch += [(m._parameters, k) for k in m._parameters] + [(m._buffers, k) for k in m._buffers]
             self.__dict__["_mirx_watch"] = watch
-        return sum(t._version for t in watch)
+        ver = ident = 0
+        for d, k in watch:
+            t = d[k]
+            if t is not None:
+                ver += t._version
+                ident += id(t)
+        return ver, ident
 
     def _cache(self):
         ver = self._weights_version()
         if self._infer_cache is None or self._infer_cache.get("_version") != ver:
             self._prepare_inference()
+            if next(self.densenet121[0].parameters()).is_cuda:
+                self._prepare_h2(self._infer_cache)
+                # the folded / split weights are built by kernels on the CALLING stream; a first use from several streams
+                # at once (bench.py's embed streams) must not read them half-built: one device-wide wait per rebuild
+                torch.cuda.synchronize(next(self.densenet121[0].parameters()).device)
             self._infer_cache["_version"] = ver
         return self._infer_cache
 
@@ -777,6 +764,7 @@ class DenseNet121(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._infer_cache = None
+        self.__dict__.pop("_mirx_watch", None)
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
@@ -862,10 +850,9 @@ class DenseNet121(nn.Module):
                 for lname, layer in m.items():
                     sc1, sh1, w1, b1 = cache[name][lname][0], cache[name][lname][1], cache[name][lname][2], cache[name][lname][3]
                     w2, osc = _split2h_weights(w1.view(w1.shape[0], w1.shape[1]))
-                    c3w2, c3osc = _conv3x3_weights_split2h(layer.conv2.weight)
-                    c3w2p, _ = _conv3x3_weights_split2h(layer.conv2.weight, YTERMS_CHANNEL_ORDER)
-                    blk[lname] = {"sc1": sc1, "sh1": sh1, "b1": b1, "w2": w2, "osc": osc, "c3w2": c3w2, "c3osc": c3osc,
-                                  "c3w2p": c3w2p, "u": cache[name][lname][6][0], "ks": float(sc1.abs().max()),
+                    c3w2p, c3osc = _conv3x3_weights_split2h(layer.conv2.weight, YTERMS_CHANNEL_ORDER)
+                    blk[lname] = {"sc1": sc1, "sh1": sh1, "b1": b1, "w2": w2, "osc": osc, "c3osc": c3osc,
+                                  "c3w2p": c3w2p, "ks": float(sc1.abs().max()),
                                   "kb": float(sh1.abs().max()),
                                   # |relu(W x + b)| <= max_o sum_c |W[o, c]| * max|x| + max|b|: the bottleneck's bound
                                   "yks": float(w1.view(w1.shape[0], -1).abs().sum(dim=1).max()), "ykb": float(b1.abs().max())}
@@ -892,25 +879,38 @@ class DenseNet121(nn.Module):
         blocks = [(n, m) for n, m in f.named_children() if n.startswith("denseblock")]
         trans = [n for n, _ in f.named_children() if n.startswith("transition")]
         nlayers = sum(len(m) for _, m in blocks)
-        ranges = torch.zeros((len(blocks) + nlayers + 1, 64), dtype=torch.float32, device=dev)  # one fill per forward
-        side = 56
-        buf = torch.empty((b, blocks[0][1].cout, _plane_stride(side)), dtype=torch.float32, device=dev)    # [B, C, plane]
+        # range rows: one float per (buffer, image) -- the blocks' buffers, every layer's bottleneck scale, the input images
+        ranges = torch.zeros((len(blocks) + nlayers + 1, b), dtype=torch.float32, device=dev)   # one fill per forward
         sc, sh = cache["norm0"]
-        xr = ranges[len(blocks) + nlayers]                           # the range of the input images: one pass over them
-        _lib.check(lib.mirx_range_absmax(_ptr(x), x.numel(), _ptr(xr), st), "mirx_range_absmax")
+        xr = ranges[len(blocks) + nlayers]                           # the range of every input image: one pass over them
+        _lib.check(lib.mirx_range_absmax(_ptr(x), x[0].numel(), b, _ptr(xr), st), "mirx_range_absmax")
         w2, osc = cache["conv0_w2"]
-        _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split2h_into(_ptr(x), _ptr(w2), _ptr(osc), _ptr(sc), _ptr(sh), b, 224, 224,
-                                                                 _ptr(buf), blocks[0][1].cout * side * side, _ptr(xr),
-                                                                 _ptr(ranges[0]), st), "mirx_stem_split2h_into")
-        row = len(blocks)
-        for k, (name, blk) in enumerate(blocks):
-            _dense_block_h2(blk, buf, side, ranges[k], h2[name], ranges[row:row + len(blk)], self.conv1x1_timer)
-            row += len(blk)
-            if k + 1 < len(blocks):
-                nxt = torch.empty((b, blocks[k + 1][1].cout, _plane_stride(side // 2)), dtype=torch.float32, device=dev)
-                _transition_h2(buf, side, h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
-                side //= 2
+        sides = [56 >> k for k in range(len(blocks))]
+        rows = [len(blocks) + sum(len(m) for _, m in blocks[:k]) for k in range(len(blocks))]
+
+        def stem(xs, dst):
+            _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split2h_into(_ptr(xs), _ptr(w2), _ptr(osc), _ptr(sc), _ptr(sh),
+                                                                     xs.shape[0], 224, 224, _ptr(dst),
+                                                                     dst.shape[1] * dst.shape[2], _ptr(xr), _ptr(ranges[0]), st),
+                       "mirx_stem_split2h_into")
+
+        def block_and_transition(k, bk, nxt):
+            name, blk = blocks[k]
+            _dense_block_h2(blk, bk, sides[k], ranges[k], h2[name], ranges[rows[k]:rows[k] + len(blk)], self.conv1x1_timer)
+            if nxt is not None:
+                _transition_h2(bk, sides[k], h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
+
+        def new_buf(k, n):
+            return torch.empty((n, blocks[k][1].cout, _plane_stride(sides[k])), dtype=torch.float32, device=dev)
+
+        buf = new_buf(0, b)
+        stem(x, buf)
+        for k in range(len(blocks)):
+            nxt = new_buf(k + 1, b) if k + 1 < len(blocks) else None
+            block_and_transition(k, buf, nxt)
+            if nxt is not None:
                 buf = nxt
+        side = sides[-1]
         buf = buf.view(b, buf.shape[1], side, side)                 # the 7 x 7 planes are packed
         self.__dict__["_mirx_last_ranges"] = ranges            # kept for diagnostics (tools/h2_state_probe.py)
         return buf

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 100
+#define MIRX_VERSION 300
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -189,20 +189,21 @@ int mirx_conv1x1_bn_relu_split3(const float *x, int64_t x_batch_stride, int cin,
                                 void *stream);
 
 /*
- * mirx_conv1x1_bn_relu_split3 with TWO fp16 terms per operand (three MFMAs per product block instead of six).  fp16
- * has 5 exponent bits, so the range of the input travels with it: `in_range_or_null` = device fp32 [64] "range slots"
- * whose maximum bounds |x| over the channel prefix the kernel reads (every mirx kernel that writes into a dense
- * block's buffer publishes the largest |value| it wrote there, unsigned atomic max on the float bits; the caller
- * zeroes the slots once per forward); the kernel stages act_in(x) * 2^s with
- *     bound = in_ks * max(slots) + in_kb         (in_ks = max |scale1|, in_kb = max |shift1|; 1, 0 without prologue;
- *                                                 slots NULL: bound = in_kb, a caller-proved constant)
- * and s chosen so that bound * 2^s is in [2^14, 2^15).  A non-finite range makes the whole output NaN (never a silently
- * wrong finite value).  w2 = device fp16 [cout / 128][cin / 16][2][128][16]: the two terms of W[co, k] * ws[co], ws a
- * power of two per output channel (mirx.model._split2h_weights); oscale = device fp32 [cout] = 1 / ws.
- * `out_range_or_null`: range slots that receive the largest |y| written (device fp32 [64], atomic max).
- * x_plane_stride / y_plane_stride: floats between consecutive channel planes of x / y (0 = hw, packed planes).  A dense
- * block's buffer may pad its planes to a multiple of 32 floats: with 784-byte planes (14 x 14) a wave's 256-byte load
- * straddles three 128-byte lines instead of two, which costs 15 % of the layer (measured: 3.5 vs 4.1 TB/s).
+ * The two-fp16-term DenseNet path (224 x 224 inputs).  fp16 has 5 exponent bits, so the RANGE of every buffer travels with
+ * it, PER IMAGE: a "range row" is device fp32 [n] (one float per image of the call, zeroed by the caller once per forward);
+ * every mirx kernel that writes image b of a dense block's buffer folds the largest |value| it wrote into row[b] (unsigned
+ * atomic max on the float bits), and every kernel that reads image b scales what it stages by a power of two derived from
+ * row[b] alone.  An image's arithmetic therefore does not depend on its batch mates; a non-finite value makes THAT image's
+ * outputs NaN (never a silently wrong finite value) and leaves the others untouched.
+ *
+ * mirx_conv1x1_bn_relu_split2h: mirx_conv1x1_bn_relu_split3 with TWO fp16 terms per operand (three MFMAs per product block
+ * instead of six).  `in_range_or_null` = range row of x; the kernel stages act_in(x_b) * 2^s with
+ *     bound_b = in_ks * row[b] + in_kb         (in_ks = max |scale1|, in_kb = max |shift1|; 1, 0 without prologue;
+ *                                               row NULL: bound = in_kb, a caller-proved constant)
+ * and s chosen so that bound_b * 2^s is in [2^14, 2^15).  w2 = device fp16 [cout / 128][cin / 16][2][128][16]: the two terms
+ * of W[co, k] * ws[co], ws a power of two per output channel (mirx.model._split2h_weights); oscale = device fp32 [cout] =
+ * 1 / ws.  `out_range_or_null`: range row of y.
+ * x_plane_stride / y_plane_stride: floats between consecutive channel planes of x / y (0 = hw, packed planes).
  * Otherwise the contract of mirx_conv1x1_bn_relu_split3 (reference: the conv1 / transition conv calls inside
  * torchvision densenet121, model.py:53-60).
  */
@@ -212,15 +213,6 @@ int mirx_conv1x1_bn_relu_split2h(const float *x, int64_t x_batch_stride, int cin
                                  int64_t y_batch_stride, const float *in_range_or_null, float in_ks, float in_kb,
                                  float *out_range_or_null, int64_t x_plane_stride, int64_t y_plane_stride, void *stream);
 
-/* DenseNet transition (norm -> relu -> conv 1x1 -> avgpool 2x2, torchvision _Transition) in ONE launch: the average pool is
- * moved in front of the (linear) convolution and into its staging -- a staged value is the mean of relu(bn(x)) over the
- * 2 x 2 input pixels -- so neither the normalised map nor the pooled map exists in memory.  x = [n, >= cin, h, w] with
- * batch stride x_batch_stride, y = [n, cout, h/2, w/2] at y_batch_stride (the channel prefix of the next block's buffer);
- * two fp16 terms, ranges as mirx_conv1x1_bn_relu_split2h (in_ks / in_kb = max |scale| / max |shift|). */
-int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch_stride, int cin, const float *scale,
-                                                 const float *shift, const void *w2, const float *oscale, int64_t n, int h,
-                                                 int w, int cout, float *y, int64_t y_batch_stride, const float *in_range,
-                                                 float in_ks, float in_kb, float *out_range_or_null, void *stream);
 /*
  * The dense layer with the 128-channel bottleneck handed over ALREADY SPLIT into its two fp16 terms (same bytes as fp32,
  * but the 3x3 conv then stages it by LDS DMA alone -- no register prefetch, no split, no LDS stores -- and the 1x1 conv
@@ -228,14 +220,17 @@ int mirx_transition_bn_relu_pool_conv1x1_split2h(const float *x, int64_t x_batch
  *   mirx_conv1x1_bn_relu_split2h_terms: mirx_conv1x1_bn_relu_split2h for cout = 128 with relu, writing
  *       y_terms = device fp16 [n][8 groups][2 terms][hw][16]: group g holds the 16 channels
  *       64 (g >> 2) + 32 ((g >> 1) & 1) + 4 (g & 1) + {0..3, 8..11, 16..19, 24..27} (mirx.model.YTERMS_CHANNEL_ORDER; the
- *       consumer's weights use the same order), values scaled by 2^t where |y| <= y_ks * (in_ks * range + in_kb) + y_kb
+ *       consumer's weights use the same order), image b scaled by 2^t where |y_b| <= y_ks * bound_b + y_kb
  *       (y_ks = max_o sum_c |W[o, c]|, y_kb = max |bias|: a bound known before the kernel runs) is brought into
- *       [2^14, 2^15); y_inv_out[0] receives 2^-t.
- *   mirx_conv3x3_direct_terms_nchw: mirx_conv3x3_direct_split2h_nchw reading such y_terms and y_inv; the padding ring of the
- *       staged strip comes from out-of-range buffer loads (zero), w2 in the permuted channel order.  side 56 / 28 / 14, and
- *       7 (four whole images per workgroup, each with its own zero ring).
+ *       [2^14, 2^15); y_inv_out = device fp32 [n] receives 2^-t of every image.
+ *   mirx_conv3x3_direct_terms_nchw: the 3x3 conv (128 -> 32, pad 1) as a direct implicit GEMM on such y_terms and y_inv
+ *       (device fp32 [n]); the padding ring of the staged strip comes from out-of-range buffer loads (zero); w2 = device fp16
+ *       [8 stages][9 taps][2 terms][32 oc][16 c] in the permuted channel order, scaled per output channel by a power of two
+ *       (mirx.model._conv3x3_weights_split2h), oscale = device fp32 [32] = 1 / that scale.  side 56 / 28 / 14, and 7 (four
+ *       whole images per workgroup, each with its own zero ring).  `out_range_or_null`: range row of `out`.
  *   x_plane_stride / out_plane_stride: floats between consecutive channel planes of the dense block's buffer (0 = packed,
- *       hw resp. side^2; see mirx_conv1x1_bn_relu_split2h).
+ *       hw resp. side^2).
+ * (reference: the conv1 / conv2 calls inside torchvision densenet121, model.py:53-60)
  */
 int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, int cin, const float *scale1,
                                        const float *shift1, const void *w2, const float *oscale, const float *bias,
@@ -244,41 +239,17 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
                                    int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                                    int64_t out_plane_stride, void *stream);
-/* The same contract on v_mfma_f32_16x16x32_f16 (k_conv3x3_d2q.hip): the A/B arm of the power-limit study -- the clock under
- * it is 1.6 instead of 1.3 GHz, the layer takes the same time.  Kept callable so that it stays tested. */
-int mirx_conv3x3_direct_terms_nchw_mfma16(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side,
-                                          float *out, int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
-                                          int64_t out_plane_stride, void *stream);
 
-/*
- * Range-publishing forms of the DenseNet producers (the two-fp16-term kernels need the range of what they read; see
- * mirx_conv1x1_bn_relu_split2h).  `out_range_or_null` = device fp32 [64] range slots of the destination buffer; every
- * workgroup folds the largest |value| it wrote into slot (workgroup % 64) with an unsigned atomic max.
- *   mirx_stem_conv7_bn_relu_pool_split3_into: mirx_stem_conv7_bn_relu_pool_split3 writing image b at y + b *
- *       y_batch_stride (the channel prefix of dense block 1's buffer: no copy).
- *   mirx_conv3x3_winograd_nchw_ranged: mirx_conv3x3_winograd_nchw + range.
- *   mirx_conv3x3_direct_split2h_nchw: the 3x3 conv (128 -> 32, pad 1) as a direct implicit GEMM on two fp16 terms per
- *       operand (three MFMAs per product block); `in_range` = range slots of x (published by the 1x1 conv that wrote it);
- *       w2 = device fp16 [8 stages][9 taps][2 terms][32 oc][16 c], scaled per output channel by a power of two
- *       (mirx.model._conv3x3_weights_split2h), oscale = device fp32 [32] = 1 / that scale.  side 56 / 28 / 14.
- * (reference: the conv0 / conv2 calls inside torchvision densenet121, model.py:53-60)
- */
-/* mirx_range_absmax: folds the largest |x[i]| of a flat fp32 array into 64 range slots (zeroed by the caller) -- the range of
- * the input images for mirx_stem_conv7_bn_relu_pool_split2h_into, the stem on two fp16 terms per operand (w2 = device fp16
- * [2][11][2][32][16], oscale = device fp32 [64]: mirx.model._stem_weights_split2h; otherwise the contract of
- * mirx_stem_conv7_bn_relu_pool_split3_into). */
-int mirx_range_absmax(const float *x, int64_t n, float *range_slots, void *stream);
+/* mirx_range_absmax: range_row[b] = max(range_row[b], largest |x| of image b), x = n images of `per_image` contiguous
+ * fp32 each -- the range of the input images for mirx_stem_conv7_bn_relu_pool_split2h_into, the stem (conv 7x7 / 2 + norm0 +
+ * relu0 + maxpool 3x3 / 2, one kernel) on two fp16 terms per operand: w2 = device fp16 [2][11][2][32][16], oscale = device
+ * fp32 [64] (mirx.model._stem_weights_split2h); image b is written at y + b * y_batch_stride (the channel prefix of dense
+ * block 1's buffer: no copy); in_range = range row of x, out_range_or_null = range row of y.  n <= 65535.
+ * (reference: conv0 / norm0 / relu0 / pool0 of torchvision densenet121, model.py:53-60) */
+int mirx_range_absmax(const float *x, int64_t per_image, int64_t n, float *range_row, void *stream);
 int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, const float *oscale, const float *scale,
                                               const float *shift, int64_t n, int h, int w, float *y, int64_t y_batch_stride,
                                               const float *in_range, float *out_range_or_null, void *stream);
-int mirx_stem_conv7_bn_relu_pool_split3_into(const float *x, const void *w3, const float *scale, const float *shift,
-                                             int64_t n, int h, int w, float *y, int64_t y_batch_stride,
-                                             float *out_range_or_null, void *stream);
-int mirx_conv3x3_winograd_nchw_ranged(const float *x, const float *u, int64_t n, int side, float *out,
-                                      int64_t out_batch_stride, float *out_range_or_null, void *stream);
-int mirx_conv3x3_direct_split2h_nchw(const float *x, const void *w2, const float *oscale, int64_t n, int side, float *out,
-                                     int64_t out_batch_stride, const float *in_range, float *out_range_or_null,
-                                     void *stream);
 
 /*
  * Memory-bound glue of the token-major backbones, so that their forward runs without a library kernel:
@@ -365,7 +336,6 @@ int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image
 /*
  * Global response normalisation of ConvNeXtV2 (timm GlobalResponseNorm, channels last) as two HBM passes:
  *   mirx_grn_norm_nhwc:  gx[b, c] = || x[b, :, c] ||_2              x = device fp32 [n, hw, c], gx = [n, c]
- *   mirx_grn_apply_nhwc: x[b, p, c] = x[b, p, c] * scale[b, c] + shift[c]  in place (c % 4 == 0)
  * with scale = 1 + weight * gx / (mean_c gx + 1e-6) and shift = bias formed by the caller on [n, c].
  * n <= 65535.  Fixed summation order (bit-reproducible).
  */
@@ -376,7 +346,6 @@ int mirx_grn_norm_nhwc(const float *x, int64_t n, int hw, int c, float *gx, void
  * scale_max[0] first. */
 int mirx_grn_scale(const float *gx, const float *weight, int64_t n, int c, float eps, float *scale, float *scale_max,
                    void *stream);
-int mirx_grn_apply_nhwc(float *x, int64_t n, int hw, int c, const float *scale, const float *shift, void *stream);
 
 /*
  * 3x3 convolution of a DenseNet dense layer (128 -> 32 channels, stride 1, pad 1, no bias): conv2 of

@@ -173,7 +173,7 @@ def test_linear_split2h_nchw_matches_float64(n_img, tpi, k, n, use_res, xmax, lo
 
 
 @pytest.mark.parametrize("n,hw,c", [(3, 144, 512), (2, 577, 192), (1, 5, 4), (4, 2304, 1024)])
-def test_grn_kernels_match_torch(n, hw, c):
+def test_grn_norm_kernel_matches_torch(n, hw, c):
     from mirx import _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -183,12 +183,6 @@ def test_grn_kernels_match_torch(n, hw, c):
     _lib.check(lib.mirx_grn_norm_nhwc(_vp(x), n, hw, c, _vp(gx), None), "mirx_grn_norm_nhwc")
     want = torch.linalg.vector_norm(x.double(), ord=2, dim=1)
     assert float(((gx.double() - want) / want).abs().max()) < 2e-6
-    scale = torch.randn(n, c, device=dev)
-    shift = torch.randn(c, device=dev)
-    y = x.clone()
-    _lib.check(lib.mirx_grn_apply_nhwc(_vp(y), n, hw, c, _vp(scale), _vp(shift), None), "mirx_grn_apply_nhwc")
-    assert torch.equal(y, torch.addcmul(shift, x, scale[:, None, :]).float()) or \
-        float((y - (x * scale[:, None, :] + shift)).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("n,c", [(3, 512), (64, 4096), (1, 7), (5, 1031)])

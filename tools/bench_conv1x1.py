@@ -43,9 +43,8 @@ def main():
         ctot = c0 + 32 * nl
         buf = torch.randn(a.batch, ctot, hw, generator=g, device=dev)
         y = torch.empty(a.batch, 128, hw, device=dev)
-        slots_in = torch.zeros(64, device=dev)
-        slots_in[3] = float(buf.abs().max())
-        slots_out = torch.zeros(64, device=dev)
+        slots_in = torch.full((a.batch,), float(buf.abs().max()), device=dev)      # range rows: one float per image
+        slots_out = torch.zeros(a.batch, device=dev)
         layers = []
         for i in range(nl):
             cin = c0 + 32 * i
@@ -81,9 +80,8 @@ def main():
     bias = torch.randn(128, generator=g, device=dev)
     w2, osc = _split2h_weights(w)
     w3 = _split3_weights(w)
-    slots_in = torch.zeros(64, device=dev)
-    slots_in[7] = float(buf.abs().max())
-    slots_out = torch.zeros(64, device=dev)
+    slots_in = torch.full((n,), float(buf.abs().max()), device=dev)
+    slots_out = torch.zeros(n, device=dev)
     want = torch.relu(torch.einsum("oc,bcp->bop", w.double(),
                                    torch.relu(buf[:, :cin].double() * sc.double()[None, :, None] + sh.double()[None, :, None]))
                       + bias.double()[None, :, None])

@@ -30,19 +30,16 @@ def main():
     for side in (56, 28, 14, 7):
         x = torch.relu(torch.randn(a.batch, 128, side, side, generator=g, device=dev))
         out = torch.empty(a.batch, 32, side, side, device=dev)
-        rin = torch.zeros(64, device=dev)
-        rin[0] = float(x.max())
-        rout = torch.zeros(64, device=dev)
+        rout = torch.zeros(a.batch, device=dev)                 # range row: one float per image
         bs = 32 * side * side
-        kinds = {"wino": lambda: lib.mirx_conv3x3_winograd_nchw_ranged(vp(x), vp(u), a.batch, side, vp(out), bs, vp(rout), None)}
+        kinds = {"wino": lambda: lib.mirx_conv3x3_winograd_nchw(vp(x), vp(u), a.batch, side, vp(out), bs, None)}
         if side != 7:
             kinds["wino3"] = lambda: lib.mirx_conv3x3_winograd_split3_nchw(vp(x), vp(u3), a.batch, side, vp(out), bs, None)
             kinds["direct3"] = lambda: lib.mirx_conv3x3_direct_split3_nchw(vp(x), vp(w3), a.batch, side, vp(out), bs, None)
-            kinds["direct2h"] = lambda: lib.mirx_conv3x3_direct_split2h_nchw(vp(x), vp(w2), vp(osc), a.batch, side, vp(out), bs,
-                                                                            vp(rin), vp(rout), None)
+        if True:
             # terms path: the bottleneck pre-split into fp16 terms [n][8][2][hw][16] (timing only: random planes)
             yt = (torch.randn(a.batch, 8, 2, side * side, 16, generator=g, device=dev) * 100).half()
-            yinv = torch.full((1,), 2.0 ** -7, device=dev)
+            yinv = torch.full((a.batch,), 2.0 ** -7, device=dev)
             kinds["terms"] = lambda: lib.mirx_conv3x3_direct_terms_nchw(vp(yt), vp(w2), vp(osc), a.batch, side, vp(out), bs,
                                                                         vp(yinv), vp(rout), 0, None)
         for name, fn in kinds.items():

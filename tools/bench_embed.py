@@ -27,8 +27,6 @@ def main():
     ap.add_argument("--no-grn-kernel", action="store_true", help="ConvNeXtV2: GRN scale vector through ATen")
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
-    ap.add_argument("--no-fused-transition", action="store_true", help="DenseNet: separate bn+relu+avgpool pass before the transition conv")
-    ap.add_argument("--conv3x3", default=None, help="DenseNet two-fp16 path: kernel for the 56/28/14/7 maps (terms | direct2h | wino), e.g. terms,terms,terms,wino")
     a = ap.parse_args()
     if a.no_split3_linear:
         import mirx.model as mm
@@ -42,11 +40,6 @@ def main():
         mm.SPLIT2H_ATTENTION = False
     for kv in filter(None, a.plane_stride.split(",")):
         mm.PLANE_STRIDE_H2[int(kv.split(":")[0])] = int(kv.split(":")[1])
-    if a.no_fused_transition:
-        mm.FUSED_TRANSITION_POOL = False
-    if a.conv3x3:
-        for side_, kind_ in zip((56, 28, 14, 7), a.conv3x3.split(',')):
-            mm.CONV3X3_KERNEL_H2[side_] = kind_
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     if a.model == "convnextv2":

@@ -9,9 +9,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mirx.model as mm  # noqa: E402
 from oracle import densenet as OD  # noqa: E402
 
-if os.environ.get("PROBE_WINO"):
-    for k_ in (56, 28, 14):
-        mm.CONV3X3_KERNEL_H2[k_] = "wino"
 torch.manual_seed(0)
 m = mm.DenseNet121().eval()
 sd = OD.randomize_bn_stats(m.state_dict(), seed=1)
