@@ -74,6 +74,8 @@ SYMBOLS = {
     "mirx_stem_conv7_bn_relu_pool_split2h_into": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split2h_terms": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i64, _vp]),
+    "mirx_dense_layer_fused": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),

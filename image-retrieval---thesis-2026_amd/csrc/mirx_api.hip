@@ -773,6 +773,27 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
     return MIRX_OK;
 }
 
+int mirx_dense_layer_fused(float *buf, int64_t batch_stride, int64_t plane_stride, int cin, const float *scale1,
+                           const float *shift1, const void *w2, const float *oscale, const float *bias, const void *c3w2,
+                           const float *c3oscale, int64_t n, int side, float *range_row, float in_ks, float in_kb, float y_ks,
+                           float y_kb, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= (int64_t)1 << 30, "dense_layer_fused: bad batch");
+    MIRX_CHECK(side == 14 || side == 7, "dense_layer_fused: side must be 14 or 7 (the bottleneck of a 196-pixel unit fits the LDS)");
+    MIRX_CHECK(cin >= 128 && cin <= 1024 && cin % 32 == 0, "dense_layer_fused: cin must be a multiple of 32 in [128, 1024]");
+    if (!plane_stride) plane_stride = (int64_t)side * side;
+    MIRX_CHECK(plane_stride == (int64_t)side * side, "dense_layer_fused: channel planes must be packed (plane stride 0 or side^2)");
+    MIRX_CHECK(batch_stride >= (int64_t)(cin + 32) * plane_stride && batch_stride % 4 == 0,
+               "dense_layer_fused: batch stride smaller than cin + 32 planes, or not a multiple of 4 floats");
+    MIRX_CHECK((reinterpret_cast<uintptr_t>(buf) & 15) == 0, "dense_layer_fused: buf must be 16-byte aligned");
+    MIRX_CHECK(n == 0 || (buf && scale1 && shift1 && w2 && oscale && bias && c3w2 && c3oscale && range_row),
+               "dense_layer_fused: null buffer");
+    MIRX_CHECK(in_ks >= 0.f && in_kb >= 0.f && y_ks >= 0.f && y_kb >= 0.f, "dense_layer_fused: bounds are non-negative");
+    MIRX_HIP(launch_dense_fused(buf, batch_stride, cin, scale1, shift1, reinterpret_cast<const uint16_t *>(w2), oscale,
+                                bias, reinterpret_cast<const uint16_t *>(c3w2), c3oscale, n, side, range_row, in_ks, in_kb, y_ks,
+                                y_kb, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const float *bias_or_null, int n, int act,
                        const float *residual_or_null, const float *gamma_or_null, float *y, void *stream) {
     MIRX_CHECK(m >= 0 && k >= 16 && k % 16 == 0 && n >= 1, "linear_split3: k must be a multiple of 16");

@@ -106,6 +106,11 @@ hipError_t launch_conv3x3_d3(const float *x, const uint16_t *w3, int64_t n, int 
 // ---- k_conv3x3_d2h.hip: the direct implicit GEMM on two fp16 terms per operand; ranges travel in range slots ------
 // w2 = [8 stages][9 taps][2 terms][32 oc][16 c] fp16 (scaled per output channel), oscale = [32] fp32
 
+// ---- k_dense_fused.hip: a whole dense layer of the 14 x 14 / 7 x 7 maps, bottleneck resident in LDS --------------------
+hipError_t launch_dense_fused(float *buf, int64_t bs, int cin, const float *scale, const float *shift, const uint16_t *w2,
+                              const float *oscale, const float *bias, const uint16_t *w3, const float *c3osc, int64_t n,
+                              int side, float *range_row, float in_ks, float in_kb, float y_ks, float y_kb, hipStream_t st);
+
 // ---- k_norm.hip: LayerNorm over rows, patchify (+ LayerNorm2d), attention for short query sets ------------------
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
                                  float *y, int tokens_per_image, hipStream_t st);

@@ -89,10 +89,11 @@ def _timer_start(timer):
     return ev
 
 
-def _timer_stop(timer, ev, flops):
+def _timer_stop(timer, ev, flops, nbytes=0.0, kind="conv1x1"):
+    """(start event, stop event, FLOP, algorithmic bytes, kernel family) per launch."""
     if timer is not None:
         ev[1].record()
-        timer.append((ev[0], ev[1], flops))
+        timer.append((ev[0], ev[1], flops, nbytes, kind))
 
 
 def _fused_bn_relu(lib, buf, c, scale, shift):
@@ -220,28 +221,39 @@ def _plane_stride(side):
     return ps
 
 
-def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None):
+def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None, fused_small=False):
     """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, plane stride] (side x side pixels per plane, see
     _plane_stride) already holds the first block.cin channels and `brange` (range row [B]: one float per image) bounds them.
-    Every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT into fp16
-    terms, image b scaled by a bound derived from brange[b] before the kernel runs (2^-t goes to the layer's row of
-    `lranges`); conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange
-    (7 x 7 maps: four images per workgroup)."""
+    56 / 28 maps, every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT
+    into fp16 terms, image b scaled by a bound derived from brange[b] before the kernel runs (2^-t goes to the layer's row of
+    `lranges`); conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange.
+    14 / 7 maps with `fused_small`: ONE launch per layer, mirx_dense_layer_fused -- the bottleneck of a 196-pixel unit stays in
+    the CU's LDS; bit-identical to the two launches and, so far, slower than them, hence opt-in."""
     lib = _lib.load()
     b, _, ps = buf.shape
     h = w = side
     st = _stream(buf.device)
     c = block.cin
-    y = torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)      # the bytes of an fp32 map, as terms
+    fused = fused_small and side in (14, 7) and ps == h * w          # the fused kernel wants packed planes
+    y = None if fused else torch.empty((b, BN_SIZE * GROWTH, h, w), dtype=torch.float32, device=buf.device)   # fp32 bytes, as terms
     for li, name in enumerate(block.keys()):
         e = cache[name]
-        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * ps)
         ev = _timer_start(timer)
+        if fused:
+            _lib.check(lib.mirx_dense_layer_fused(_ptr(buf), block.cout * ps, ps, c, _ptr(e["sc1"]), _ptr(e["sh1"]), _ptr(e["w2"]),
+                                                  _ptr(e["osc"]), _ptr(e["b1"]), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, side,
+                                                  _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"], st),
+                       "mirx_dense_layer_fused")
+            _timer_stop(timer, ev, 2.0 * b * h * w * (c * BN_SIZE * GROWTH + 9 * BN_SIZE * GROWTH * GROWTH),
+                        4.0 * b * h * w * (c + GROWTH), "dense_fused")
+            c += GROWTH
+            continue
+        dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * ps)
         _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(_ptr(buf), block.cout * ps, c, _ptr(e["sc1"]), _ptr(e["sh1"]),
                                                           _ptr(e["w2"]), _ptr(e["osc"]), _ptr(e["b1"]), b, h * w, _ptr(y),
                                                           _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
                                                           _ptr(lranges[li]), ps, st), "mirx_conv1x1_bn_relu_split2h_terms")
-        _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1])
+        _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1], 4.0 * b * h * w * (c + y.shape[1]), "conv1x1")
         _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
                                                       block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
                    "mirx_conv3x3_direct_terms_nchw")
@@ -269,7 +281,7 @@ def _transition_h2(buf, side, cache, brange, next_buf, next_range, timer=None):
                                                 None, b, hw2, c // 2, 0, _ptr(next_buf), next_buf.shape[1] * nps,
                                                 _ptr(brange), cache["ks"], cache["kb"], _ptr(next_range), 0, nps, st),
                "mirx_conv1x1_bn_relu_split2h")
-    _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2))
+    _timer_stop(timer, ev, 2.0 * b * hw2 * c * (c // 2), 4.0 * b * hw2 * (c + c // 2), "conv1x1")
     return next_buf
 
 
@@ -711,6 +723,8 @@ class DenseNet121(nn.Module):
                                            # (measured faster than the fp32-MFMA kernel on every DenseNet-121 layer)
         self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
+        self.fused_small_maps = False      # True: 14 x 14 / 7 x 7 dense layers in ONE launch, bottleneck resident in LDS
+                                           # (mirx_dense_layer_fused: bit-identical, measured 4-6 % slower so far -- DESIGN 6.3)
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
@@ -896,7 +910,8 @@ class DenseNet121(nn.Module):
 
         def block_and_transition(k, bk, nxt):
             name, blk = blocks[k]
-            _dense_block_h2(blk, bk, sides[k], ranges[k], h2[name], ranges[rows[k]:rows[k] + len(blk)], self.conv1x1_timer)
+            _dense_block_h2(blk, bk, sides[k], ranges[k], h2[name], ranges[rows[k]:rows[k] + len(blk)], self.conv1x1_timer,
+                            self.fused_small_maps)
             if nxt is not None:
                 _transition_h2(bk, sides[k], h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
 

@@ -240,6 +240,22 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
                                    int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                                    int64_t out_plane_stride, void *stream);
 
+/*
+ * mirx_dense_layer_fused: the dense layer of the 14 x 14 and 7 x 7 maps (dense blocks 3 and 4) in ONE launch --
+ *     buf[b, cin : cin + 32] = conv2_3x3( relu( conv1_1x1( relu( buf[b, 0 : cin] * scale1 + shift1 ) ) + bias ) )
+ * with the 128-channel bottleneck of a 196-pixel unit (one 14 x 14 image, four 7 x 7 images) kept in the CU's LDS: it never
+ * reaches HBM.  Arguments as mirx_conv1x1_bn_relu_split2h_terms (w2, oscale, bias, in_ks, in_kb, y_ks, y_kb) and
+ * mirx_conv3x3_direct_terms_nchw (c3w2 in the permuted channel order, c3oscale); buf = device fp32 [n, >= cin + 32, side^2]
+ * (packed planes: plane_stride 0 or side^2; 16-byte aligned) at batch_stride floats per image (a multiple of 4); range_row = the buffer's range row (device fp32 [n]): read
+ * for the input bound of every image, then raised to the largest |value| of its 32 new channels.  The 32 channels are
+ * bit-identical to the two-launch form.  cin % 32 == 0, 128 <= cin <= 1024.
+ * (reference: _DenseLayer of torchvision densenet121, model.py:53-60)
+ */
+int mirx_dense_layer_fused(float *buf, int64_t batch_stride, int64_t plane_stride, int cin, const float *scale1,
+                           const float *shift1, const void *w2, const float *oscale, const float *bias, const void *c3w2,
+                           const float *c3oscale, int64_t n, int side, float *range_row, float in_ks, float in_kb, float y_ks,
+                           float y_kb, void *stream);
+
 /* mirx_range_absmax: range_row[b] = max(range_row[b], largest |x| of image b), x = n images of `per_image` contiguous
  * fp32 each -- the range of the input images for mirx_stem_conv7_bn_relu_pool_split2h_into, the stem (conv 7x7 / 2 + norm0 +
  * relu0 + maxpool 3x3 / 2, one kernel) on two fp16 terms per operand: w2 = device fp16 [2][11][2][32][16], oscale = device

@@ -580,3 +580,89 @@ def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad):
     assert pad == 0 or bool(torch.isnan(store[:, :, hw:]).all())         # plane gaps untouched (and, being NaN, unread)
     assert bool((yinv > 0).all())
     assert torch.equal(brange, torch.maximum(rng_before, buf[:, cin:cin + 32].abs().amax(dim=(1, 2, 3))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,batch,cin,mag,pad", [(14, 1, 256, 1.0, 0), (14, 5, 512, 1e-2, 0), (14, 3, 992, 30.0, 0), (14, 2, 288, 1.0, 0),
+                                                    (14, 2, 128, 1.0, 0), (14, 3, 160, 1.0, 0), (14, 2, 192, 1.0, 0), (14, 2, 224, 1.0, 0), (14, 2, 160, 1.0, 28),
+                                                    (7, 1, 512, 1.0, 0), (7, 4, 544, 1.0, 0), (7, 9, 992, 25.0, 0), (7, 6, 640, 1.0, 0),
+                                                    (14, 300, 320, 1.0, 0), (14, 515, 352, 1.0, 0), (7, 1027, 576, 1.0, 0)])
+def test_fused_dense_layer_is_bit_identical_to_the_two_launches(side, batch, cin, mag, pad):
+    """mirx_dense_layer_fused (14 x 14 / 7 x 7 maps: 1x1 conv -> bottleneck resident in LDS -> 3x3 conv, one persistent
+    workgroup per CU) against mirx_conv1x1_bn_relu_split2h_terms + mirx_conv3x3_direct_terms_nchw on the same buffer: the 32
+    new channels and every image's range are BIT-IDENTICAL (same MFMA sequences), the float64 dense layer is met to 3e-6 per
+    image, neighbours and plane gaps untouched.  Batches that end inside a unit (7 x 7: four images per unit), more units
+    than CUs (the persistent loop and its cross-unit prefetch), stage counts with nk % 4 == 2 (the ring rotation) and the
+    shortest loops (nk = 8, 10, 12, 14: every tail of the unrolled stage loops), images of very different magnitudes."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side + cin + batch)
+    ctot = cin + 64
+    hw = side * side
+    ps = hw + pad
+    store = torch.full((batch, ctot, ps), float("nan"), device=dev)
+    buf = store[:, :, :hw].unflatten(2, (side, side))
+    buf.copy_(torch.randn(batch, ctot, side, side, generator=g, device=dev) * mag)
+    if batch > 1:
+        buf[batch - 1] *= 1e-3
+    buf[:, cin:] = 7.0 * mag
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3 * mag
+    w1 = torch.randn(128, cin, generator=g, device=dev) / cin ** 0.5
+    b1 = torch.randn(128, generator=g, device=dev) * 0.2 * mag
+    w3 = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    w2, osc = _split2h_weights(w1)
+    c3, c3osc = _conv3x3_weights_split2h(w3, YTERMS_CHANNEL_ORDER)
+    brange0 = buf[:, :cin].abs().amax(dim=(1, 2, 3)).contiguous()
+    ks, kb, yks, ykb = float(sc.abs().max()), float(sh.abs().max()), float(w1.abs().sum(dim=1).max()), float(b1.abs().max())
+    vp = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)      # noqa: E731
+    # two launches
+    store_a, range_a = store.clone(), brange0.clone()
+    y = torch.empty((batch, 128, side, side), device=dev)
+    yinv = torch.zeros(batch, device=dev)
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(store_a), ctot * ps, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), batch, hw,
+                                                      vp(y), vp(range_a), ks, kb, yks, ykb, vp(yinv), ps if pad else 0, None), "terms")
+    _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), batch, side, vp(store_a, 4 * cin * ps), ctot * ps, vp(yinv),
+                                                  vp(range_a), ps if pad else 0, None), "conv3x3_terms")
+    # one launch
+    store_b, range_b = store.clone(), brange0.clone()
+    if pad:                                                            # padded planes are refused (stage offsets are immediates)
+        assert lib.mirx_dense_layer_fused(vp(store_b), ctot * ps, ps, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), vp(c3), vp(c3osc),
+                                          batch, side, vp(range_b), ks, kb, yks, ykb, None) != 0
+        return
+    _lib.check(lib.mirx_dense_layer_fused(vp(store_b), ctot * ps, ps if pad else 0, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), vp(c3),
+                                          vp(c3osc), batch, side, vp(range_b), ks, kb, yks, ykb, None), "fused")
+    torch.cuda.synchronize()
+    a = store_a[:, :, :hw]
+    b = store_b[:, :, :hw]
+    assert torch.equal(a[:, cin:cin + 32], b[:, cin:cin + 32])
+    assert torch.equal(range_a, range_b)
+    assert torch.equal(b[:, :cin], store[:, :cin, :hw]) and bool((b[:, cin + 32:] == 7.0 * mag).all())     # prefix and neighbours untouched
+    assert pad == 0 or bool(torch.isnan(store_b[:, :, hw:]).all())
+    if batch <= 16:
+        x64 = torch.relu(buf[:, :cin].double().cpu() * sc.double().cpu()[None, :, None, None] + sh.double().cpu()[None, :, None, None])
+        y64 = torch.relu(torch.einsum("oc,bchw->bohw", w1.double().cpu(), x64) + b1.double().cpu()[None, :, None, None])
+        want = torch.nn.functional.conv2d(y64, w3.double().cpu(), None, padding=1)
+        got = b[:, cin:cin + 32].unflatten(2, (side, side)).double().cpu()
+        for i in range(batch):
+            assert float((got[i] - want[i]).abs().max()) < 3e-6 * float(want[i].abs().max()), i
+    assert lib.mirx_dense_layer_fused(vp(store_b), ctot * ps, 0, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), vp(c3), vp(c3osc), batch,
+                                      28, vp(range_b), ks, kb, yks, ykb, None) != 0                      # 28 x 28 does not fit
+
+
+@pytest.mark.gpu
+def test_fused_and_two_launch_small_maps_give_the_same_embeddings(model_and_sd):
+    m, sd = model_and_sd
+    x = torch.randn(7, 3, 224, 224, generator=torch.Generator().manual_seed(21)).cuda()
+    x[4] *= 20.0
+    with torch.no_grad():
+        two = m(x)
+        m.fused_small_maps = True
+        try:
+            fused = m(x)
+        finally:
+            m.fused_small_maps = False
+    assert torch.equal(fused, two)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--no-grn-kernel", action="store_true", help="ConvNeXtV2: GRN scale vector through ATen")
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
+    ap.add_argument("--fused-small", action="store_true", help="DenseNet: 14 / 7 maps on the one-launch dense layer (A/B arm)")
     a = ap.parse_args()
     if a.no_split3_linear:
         import mirx.model as mm
@@ -53,6 +54,7 @@ def main():
         m = DenseNet121().eval().to(dev)
         m.use_hip_stem = not a.no_hip_stem
         m.use_hip_conv1x1 = not a.no_hip_conv1x1
+        m.fused_small_maps = a.fused_small
     if a.channels_last:
         m = m.to(memory_format=torch.channels_last)
     x = torch.randn(a.batch, 3, a.size, a.size, device=dev)
