@@ -149,14 +149,41 @@ def cpu_baseline(index, model, args, dev):
 
 
 def profile_traffic(name, key):
-    """Per-launch (or per-forward) fabric-side bytes from the committed PMC summary profiles/r02_pmc_traffic.json
-    (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2 on gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        d = json.load(fh)
-    return d.get(name, {}).get(key)
+    """Fabric-side bytes from the committed PMC summary of the newest round that has one (tools/pmc_traffic.py: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2 on gfx950).  -> (value, file name) or (None, None)."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if os.path.exists(path):
+            with open(path) as fh:
+                d = json.load(fh)
+            v = d.get(name, {}).get(key)
+            if v is not None:
+                return v, os.path.basename(path)
+    return None, None
+
+
+# ---- algorithmic work of the other backbones (per image): every Linear / conv reads its input once and writes its output once
+# (fp32), elementwise steps (LayerNorm, GELU, GRN, residual, softmax) count as fused; FLOP = matrix FLOP.  The rule of SURVEY 8d.
+def convnextv2_work(size=384, dims=(128, 256, 512, 1024), depths=(3, 3, 27, 3)):
+    t = (size // 4) ** 2
+    flop, elems = 2.0 * t * 48 * dims[0], t * (48 + dims[0])                       # stem 4x4 / 4
+    for i, (c, d) in enumerate(zip(dims, depths)):
+        if i:
+            flop += 2.0 * (t // 4) * 4 * dims[i - 1] * c                           # downsample 2x2 / 2
+            elems += t * dims[i - 1] + (t // 4) * c
+            t //= 4
+        flop += d * (2.0 * 49 * c * t + 16.0 * t * c * c)                          # dwconv 7x7 + fc1 + fc2 (hidden 4 c)
+        elems += d * 12 * t * c                                                    # dw in/out, fc1 in + 4c out, fc2 4c in + out
+    return flop, 4.0 * elems
+
+
+def vit_work(tokens, c, hidden, depth, patch_k):
+    flop = 2.0 * tokens * patch_k * c + depth * (2.0 * tokens * c * (4 * c + 2 * hidden) + 4.0 * tokens * tokens * c)
+    elems = tokens * (patch_k + c) + depth * (10 * tokens * c + 2 * tokens * (c + hidden))      # qkv, attention, proj, fc1, fc2
+    return flop, 4.0 * elems
+
+
+FP32_EQ_PEAK_TFLOPS = 2516.6 / 3.0        # two fp16 terms per operand: three dense fp16 MFMAs per fp32-grade product
 
 
 def timed_images_per_s(model, x, iters, warmup=2):
@@ -171,6 +198,105 @@ def timed_images_per_s(model, x, iters, warmup=2):
     return x.shape[0] * iters / (time.perf_counter() - t0)
 
 
+def overlap_ab(model, index, pool, args, dev, steps=6):
+    """search of step i beside the embed of step i + 1 (mirx_index_search_begin / _end on its own stream, two embedding
+    buffers) against the plain sequence, same box, same run: queries/s of both.  N = 1 only."""
+    q = pool[0].shape[0]
+    embs = [torch.empty((q, args.dim), dtype=torch.float32, device=dev) for _ in range(2)]
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    sstream = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def embed(dst):
+        part = q // 2
+        for j, st in enumerate(side):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                dst[j * part:(j + 1) * part] = model(pool[0][j * part:(j + 1) * part])
+        for st in side:
+            cur.wait_stream(st)
+
+    def run(overlap):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pending = None
+        with torch.no_grad():
+            for i in range(steps):
+                buf = embs[i % 2]
+                embed(buf)
+                if not overlap:
+                    index.search(buf, args.k, return_f64=True)
+                    continue
+                sstream.wait_stream(cur)
+                if pending is not None:
+                    with torch.cuda.stream(sstream):
+                        index.search_end(pending, return_f64=True)
+                with torch.cuda.stream(sstream):
+                    pending = index.search_begin(buf, args.k)
+            if pending is not None:
+                with torch.cuda.stream(sstream):
+                    index.search_end(pending, return_f64=True)
+        torch.cuda.synchronize(dev)
+        return steps * q / (time.perf_counter() - t0)
+
+    run(False)
+    off = run(False)
+    run(True)
+    on = run(True)
+    return {"off_queries_per_s": off, "on_queries_per_s": on, "steps": steps, "queries_per_step": q,
+            "note": "on: the search of step i runs on its own stream beside the embed of step i + 1 (search_begin/_end)"}
+
+
+def host_resident_inputs(model, index, args, dev, steps=4):
+    """The reference's loop hands HOST batches to the device (test.py:1070-1075).  Here: 8-bit images in pinned host memory
+    -> device on a copy stream (double-buffered, overlapped with the previous batch's embed + search) -> uint8 stem.  The
+    PCIe-inclusive queries/s of the whole step; fp32 host images would move four times the bytes."""
+    q = args.embed_batch
+    host = [torch.randint(0, 256, (q, 3, args.image_size, args.image_size), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    devb = [torch.empty((q, 3, args.image_size, args.image_size), dtype=torch.uint8, device=dev) for _ in range(2)]
+    copy = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    emb = torch.empty((q, args.dim), dtype=torch.float32, device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        with torch.cuda.stream(copy):
+            copy.wait_event(consumed[i % 2])
+            devb[i % 2].copy_(host[i % 2], non_blocking=True)
+            ready[i % 2].record(copy)
+
+    def one(i):
+        cur.wait_event(ready[i % 2])
+        part = q // 2
+        for j, st in enumerate(side):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                emb[j * part:(j + 1) * part] = model(devb[i % 2][j * part:(j + 1) * part])
+        for st in side:
+            cur.wait_stream(st)
+        consumed[i % 2].record(cur)
+        index.search(emb, args.k, return_f64=True)
+
+    with torch.no_grad():
+        for ev in consumed:
+            ev.record(cur)
+        upload(0)
+        one(0)                                                 # warm-up step (uint8 path, pinned buffers)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        upload(0)
+        for i in range(steps):
+            if i + 1 < steps:
+                upload(i + 1)
+            one(i)
+        torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"queries_per_s": q / dt, "ms_per_step": dt * 1e3, "h2d_mb_per_step": q * 3 * args.image_size ** 2 / 1e6,
+            "input": "uint8 [B, 3, H, W] in pinned host memory, normalised inside the stem kernel", "steps": steps}
+
+
 def extras(args, dev):
     """Configs 3-5 of BASELINE.json on this GPU (embed stage, native resolution, fp32, synthetic images, random-init
     weights) and the search stage at their embedding widths over a 1M-row gallery."""
@@ -178,6 +304,8 @@ def extras(args, dev):
     from mirx.index import FlatIndex
     from mirx.model import ConvNeXtV2, DinoV2, MedSigLIP
     out = {}
+    work = {"convnextv2_base_384": convnextv2_work(384), "dinov2_vitb14_518": vit_work(37 * 37 + 1, 768, 3072, 12, 588),
+            "medsiglip_448": vit_work(32 * 32, 1152, 4304, 27, 588)}
     for name, ctor, size, batch, iters in (("convnextv2_base_384", lambda: ConvNeXtV2(embedding_dim=256), 384, 64, 4),
                                            ("dinov2_vitb14_518", lambda: DinoV2(embedding_dim=256), 518, 32, 4),
                                            ("medsiglip_448", lambda: MedSigLIP(embed_dim=512), 448, 16, 4)):
@@ -185,10 +313,18 @@ def extras(args, dev):
         m = ctor().eval().to(dev)
         x = synthetic_images(batch, size, 99, dev)
         ips = timed_images_per_s(m, x, iters)
+        flop, nbytes = work[name]
+        tr, tr_file = profile_traffic(name, "bytes_per_image")
+        tr_batch, _ = profile_traffic(name, "batch")
+        f_frac, b_frac = flop * ips / 1e12 / FP32_EQ_PEAK_TFLOPS, nbytes * ips / 1e9 / 8000.0
         out[name] = {"images_per_s": ips, "batch": batch, "image_size": size, "dtype": "f32 (two fp16 / three bf16 MFMA terms)",
                      "data": "synthetic images, random-init weights",
-                     "traffic_per_forward": profile_traffic(name, "bytes_per_forward"),
-                     "dominant_kernel": profile_traffic(name, "dominant_kernel")}
+                     "algorithmic_gflop_per_image": flop / 1e9, "algorithmic_mb_per_image": nbytes / 1e6,
+                     "roofline": {"bound": "mfma" if f_frac >= b_frac else "hbm", "frac_of_fp32_equivalent_mfma_peak": f_frac,
+                                  "frac_of_hbm_peak": b_frac, "frac": max(f_frac, b_frac),
+                                  "peaks": f"{FP32_EQ_PEAK_TFLOPS:.1f} TFLOP/s (dense fp16 MFMA / 3 terms), 8000 GB/s"},
+                     "traffic_bytes_per_image": tr, "traffic_profile": tr_file, "traffic_profile_batch": tr_batch,
+                     "dominant_kernel": profile_traffic(name, "dominant_kernel")[0]}
         del m, x
         torch.cuda.empty_cache()
     for dim in (256, 512):
@@ -405,33 +541,29 @@ def main():
         with torch.no_grad():
             model(xcal)
         torch.cuda.synchronize(dev)
-        ms = sum(a.elapsed_time(b) for a, b, _ in model.conv1x1_timer)
-        fl = sum(f for _, _, f in model.conv1x1_timer)
-        nl = len(model.conv1x1_timer)
+        fams = {}
+        for a, b, f, nb, kind in model.conv1x1_timer:
+            e = fams.setdefault(kind, [0.0, 0.0, 0.0, 0])
+            e[0] += a.elapsed_time(b)
+            e[1] += f
+            e[2] += nb
+            e[3] += 1
         model.conv1x1_timer = None
-        if ms > 0:
-            # algorithmic bytes: a launch reads cin channels and writes cout channels of every pixel once, fp32
-            # (flop = 2 * pixels * cin * cout per launch, so bytes = 4 * pixels * (cin + cout) needs the shapes: take
-            # them from the model's own geometry)
-            from mirx.model import BLOCK_CONFIG, BN_SIZE, GROWTH, INIT_FEATURES
-            b, px, c, nbytes = xcal.shape[0], (args.image_size // 4) ** 2, INIT_FEATURES, 0.0
-            for bi, nlayers in enumerate(BLOCK_CONFIG):
-                for li in range(nlayers):
-                    nbytes += 4.0 * b * px * (c + li * GROWTH + BN_SIZE * GROWTH)
-                c += nlayers * GROWTH
-                if bi + 1 < len(BLOCK_CONFIG):
-                    px //= 4
-                    nbytes += 4.0 * b * px * (c + c // 2)
-                    c //= 2
+        if fams:
+            # the dominant hand-written family of the embed stage by time (the fused 1x1 convolutions of the 58 dense layers and
+            # 3 transitions).  Algorithmic bytes: a launch reads cin channels and writes cout channels of every pixel once, fp32.
+            kind, (ms, fl, nbytes, nl) = max(fams.items(), key=lambda kv: kv[1][0])
+            b = xcal.shape[0]
             gbs = nbytes / (ms * 1e-3) / 1e9
-            tr = profile_traffic("densenet121_conv1x1", "bytes_per_image")
+            tr, tr_file = profile_traffic("densenet121_conv1x1", "bytes_per_image")
             embed_roof = {"bound": "hbm",
-                          "kernel": f"mirx::k_conv1x1_h2 (fused BN+ReLU+1x1 conv+BN+ReLU, two fp16 MFMA terms, fp32-grade), "
-                                    f"{nl} launches of one {b}-image forward",
+                          "kernel": ("mirx::k_conv1x1_h2 (fused BN+ReLU+1x1 conv+BN+ReLU, two fp16 MFMA terms, fp32-grade), "
+                                     if kind == "conv1x1" else "mirx::k_dense_fused (one-launch dense layer, bottleneck in LDS), ")
+                                    + f"{nl} launches of one {b}-image forward",
                           "dtype": "f32 (2 x fp16 terms)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                           "algorithmic_bytes_per_forward": nbytes, "ms_per_forward": ms,
                           "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
-                          "traffic": None if tr is None else tr * b}
+                          "traffic": None if tr is None else tr * b, "traffic_profile": tr_file}
     if rank == 0:
         dimp = (args.dim + 63) // 64 * 64
         flop = 2.0 * (world * q_local // max(1, args.search_chunks if world > 1 else 1)) * (hi - lo) * dimp
@@ -470,14 +602,23 @@ def main():
         if embed_roof is not None:
             line["roofline_embed"] = embed_roof
         if world == 1 and q_local == 4096 and args.gallery == 1_000_000 and args.dim == 1024:
-            line["roofline"]["traffic"] = profile_traffic("gemm_1Mx1024_q4096", "bytes_per_launch") or \
-                gemm_traffic_from_profile(args, world, q_local)
+            tr, tr_file = profile_traffic("gemm_1Mx1024_q4096", "bytes_per_launch")
+            line["roofline"]["traffic"] = tr or gemm_traffic_from_profile(args, world, q_local)
+            line["roofline"]["traffic_profile"] = tr_file
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(index, model, args, dev)
         if world == 1 and not args.no_extras and not args.search_only:
+            ab = overlap_ab(model, index, pool, args, dev) if args.embed_batch % 2 == 0 else None
+            hri = host_resident_inputs(model, index, args, dev) if args.embed_batch % 2 == 0 and args.image_size == 224 else None
             del model, index, searcher, pool
             torch.cuda.empty_cache()
             line["extras"] = extras(args, dev)
+            if ab is not None:
+                line["extras"]["overlap_search_with_embed"] = ab
+            if hri is not None:
+                line["extras"]["host_resident_inputs"] = hri
+            line["roofline"]["other_dims"] = {k: {kk: v[kk] for kk in ("gemm_ms", "gemm_tflops", "gemm_frac_of_bf16_peak")}
+                                              for k, v in line["extras"].items() if k.startswith("search_only_")}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -71,6 +71,9 @@ SYMBOLS = {
     "mirx_patchify_nchw": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, ctypes.c_float, _vp, _int, _vp]),
     "mirx_attention_small": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _int, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_range_absmax": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "mirx_range_absmax_u8": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mirx_stem_conv7_bn_relu_pool_split2h_u8_into": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp,
+                                                            _vp]),
     "mirx_stem_conv7_bn_relu_pool_split2h_into": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split2h_terms": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i64, _vp]),

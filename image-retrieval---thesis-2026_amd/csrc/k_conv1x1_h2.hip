@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                                                        unsigned *__restrict__ out_amax, float y_ks, float y_kb,
                                                        float *__restrict__ y_inv_out, int64_t xps, int64_t yps) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    __shared__ float sBias[CM], sOsc[CM];
+    constexpr int KIMG = 8;                        // images a workgroup's pixels may span with a table row each (else: multiply)
+    __shared__ float sBias[CM], sOsc[KIMG][CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
@@ -81,15 +82,16 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     const int b_kg = wave >> 1;
     const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw)
     const float *xsrc[NPT];
-    float x_scale[NPT];                                               // of this thread's pixel's image
+    float x_scale[NPT];                                               // of this thread's pixel's image (set behind the first loads)
+    unsigned st_img[NPT];
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
-        int64_t pp = p0 + u * CP + b_px;
-        int64_t b_off = 0;
-        if (pp < total) b_off = (pp / hw) * xbs + pp % hw;
-        else pp = total - 1;                                          // a dead pixel stages image 0 with a valid scale
-        float inv_;
-        range_scales(image_bound(pp / hw), x_scale[u], inv_);
+        // pixel indices fit 32 bits (checked by the launcher): one 32-bit division per pixel instead of 64-bit ones
+        const unsigned pp = (unsigned)(p0 + u * CP + b_px);
+        const bool live = pp < (unsigned)total;
+        const unsigned pimg = (live ? pp : (unsigned)total - 1u) / (unsigned)hw;     // a dead pixel: a valid image, data of image 0
+        const int64_t b_off = live ? (int64_t)pimg * xbs + (pp - pimg * (unsigned)hw) : 0;
+        st_img[u] = pimg;
         xsrc[u] = x + b_off + (int64_t)(8 * b_kg) * in_hw;
     }
     const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + tile * 2 PLANE_B + term * PLANE_B
@@ -170,6 +172,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         fb[t] = 2 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
     }
 
+    const unsigned img_first = (unsigned)p0 / (unsigned)hw;
+    const unsigned p_last = (unsigned)(p0 + CP * NPT - 1 < total ? p0 + CP * NPT - 1 : total - 1);
+    const bool tabled = p_last / (unsigned)hw - img_first < KIMG;       // workgroup-uniform: the images the pixels span fit the table
+
     f32x16 acc[2][NN];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -178,10 +184,6 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (threadIdx.x < CM) {
-        sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
-        sOsc[threadIdx.x] = oscale[co0 + threadIdx.x];
-    }
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
     auto stage = [&](int kt, int cur, float (&rnext)[NPT][NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NPT][NR],
                      const float (&scs)[8], const float (&shs)[8]) {
@@ -225,6 +227,44 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     dma_w(0, 0);
     load(0, ra, sca, sha);
     load(nk > 1 ? 1 : 0, rb, scb, shb);
+    if (threadIdx.x < CM) {
+        sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
+        const float osc = oscale[co0 + threadIdx.x];
+        sOsc[0][threadIdx.x] = osc;
+        if (tabled) {
+            const unsigned nimg = p_last / (unsigned)hw - img_first + 1;
+            for (unsigned k = 0; k < nimg; ++k) {
+                float xs_, xi_;
+                range_scales(image_bound(img_first + k), xs_, xi_);
+                sOsc[k][threadIdx.x] = osc * xi_;                       // two powers of two: exact
+            }
+        }
+    }
+    // the ranges are read only NOW, behind the first two stages of loads: a range load in front of them held every
+    // workgroup's first loads back by one memory round trip (+3 % on the layer)
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+        float inv_;
+        range_scales(image_bound(st_img[u]), x_scale[u], inv_);
+    }
+    // its image's 2^-s times oscale[channel] comes from a small LDS table, one row per image the workgroup's pixels span
+    // (built below) -- one LDS read per output value as before ranges were per image, instead of an extra multiply per value
+    float ep_xinv[NN], ep_ys[NN];
+    int ep_k[NN];
+#pragma unroll
+    for (int ni = 0; ni < NN; ++ni) {
+        unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31));
+        if (pp >= (unsigned)total) pp = (unsigned)total - 1u;
+        const unsigned pimg = pp / (unsigned)hw;
+        const float xb = image_bound(pimg);
+        float xs_, yi_;
+        range_scales(xb, xs_, ep_xinv[ni]);
+        ep_k[ni] = tabled ? (int)(pimg - img_first) : 0;
+        if (tabled) ep_xinv[ni] = 1.f;                                  // folded into the table row
+        ep_ys[ni] = 1.f;
+        if (YTERMS) range_scales(fmaf(y_ks, xb, y_kb), ep_ys[ni], yi_);
+    }
+
     store(0, ra, sca, sha);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
@@ -245,14 +285,16 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         uint16_t *yt = reinterpret_cast<uint16_t *>(y);
 #pragma unroll
         for (int ni = 0; ni < NN; ++ni) {
-            const int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
-            if (pp >= total) continue;
-            const int64_t bimg = pp / hw, off = pp % hw;
-            const float xb = image_bound(bimg);
-            float xs_, x_inv, y_scale, y_inv;
-            range_scales(xb, xs_, x_inv);
-            range_scales(fmaf(y_ks, xb, y_kb), y_scale, y_inv);
-            if (off == 0 && wm == 0 && lane < 32) y_inv_out[bimg] = y_inv;     // one writer per image: the lane of its pixel 0
+            const unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31));
+            if (pp >= (unsigned)total) continue;
+            const unsigned ubimg = pp / (unsigned)hw;
+            const int64_t bimg = ubimg, off = pp - ubimg * (unsigned)hw;
+            const float x_inv = ep_xinv[ni], y_scale = ep_ys[ni];
+            if (off == 0 && wm == 0 && lane < 32) {                            // one writer per image: the lane of its pixel 0
+                float ys_, y_inv;
+                range_scales(fmaf(y_ks, image_bound(bimg), y_kb), ys_, y_inv);
+                y_inv_out[bimg] = y_inv;
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int g = 4 * wm + 2 * mi + (lane >> 5);
@@ -264,7 +306,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * j + e;
                         const int ch = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float t = fmaf(acc[mi][ni][r], sOsc[ch] * x_inv, sBias[ch]);
+                        float t = fmaf(acc[mi][ni][r], tabled ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv, sBias[ch]);
                         t = t < 0.f ? 0.f : t;
                         v[e] = t * y_scale;
                     }
@@ -285,12 +327,13 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     }
 #pragma unroll
     for (int ni = 0; ni < NN; ++ni) {
-        int64_t pp = p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31);
-        const bool live = pp < total;
-        if (!live) pp = total - 1;                            // carries nothing: a valid image index and vmax = 0
-        const int64_t bimg = pp / hw, off = pp % hw;
-        float xs_, x_inv, vmax = 0.f;
-        range_scales(image_bound(bimg), xs_, x_inv);
+        unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31));
+        const bool live = pp < (unsigned)total;
+        if (!live) pp = (unsigned)total - 1u;                 // carries nothing: a valid image index and vmax = 0
+        const unsigned ubimg = pp / (unsigned)hw;
+        const int64_t bimg = ubimg, off = pp - ubimg * (unsigned)hw;
+        const float x_inv = ep_xinv[ni];
+        float vmax = 0.f;
         float *yo = y + bimg * ybs + off;
         if (live) {
 #pragma unroll
@@ -298,7 +341,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = fmaf(acc[mi][ni][r], sOsc[ch - co0] * x_inv, sBias[ch - co0]);
+                    float v = fmaf(acc[mi][ni][r], tabled ? sOsc[ep_k[ni]][ch - co0] : sOsc[0][ch - co0] * x_inv, sBias[ch - co0]);
                     if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
                     vmax = range_max(vmax, v);
                     yo[(int64_t)ch * yps] = v;
@@ -324,6 +367,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     if (xps < hw || yps < hw) return hipErrorInvalidValue;
     // two pixel tiles per workgroup (one staged copy of the weights for both) when the launch still fills the chip
     const int64_t px = n * (int64_t)hw;
+    if (px >= ((int64_t)1 << 31) - 2 * CP) return hipErrorInvalidValue;      // the kernel indexes pixels with 32 bits
     const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
     const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);

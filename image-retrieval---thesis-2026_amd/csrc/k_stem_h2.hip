@@ -51,12 +51,24 @@ __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
     l = __builtin_bit_cast(unsigned, vl);
 }
 
-__global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x, const uint16_t *__restrict__ w3,
+// TIN = float: normalised fp32 images.  TIN = uint8_t: raw 8-bit images [B, 3, H, W]; the reference's ToTensor + Normalize
+// (test.py:1309-1332: x = u / 255, then (x - mean[c]) / std[c], fp32, correctly rounded) is applied while the patch is staged,
+// through a 3 x 256 table built once per workgroup with exactly those operations -- the staged values, hence the embeddings,
+// are bit-identical to feeding the normalised fp32 tensor, at a quarter of the input bytes (PCIe and HBM).
+template <typename TIN>
+__global__ __launch_bounds__(256, 2) void k_stem_h2(const TIN *__restrict__ x, const uint16_t *__restrict__ w3,
                                                     const float *__restrict__ oscale, const float *__restrict__ scale,
                                                     const float *__restrict__ shift, int h, int wd, float *__restrict__ y,
                                                     int64_t y_bs, const float *__restrict__ in_range,
-                                                    unsigned *__restrict__ out_range) {
+                                                    unsigned *__restrict__ out_range, const float *__restrict__ mean,
+                                                    const float *__restrict__ stdv) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr bool U8 = sizeof(TIN) == 1;
+    __shared__ float s_lut[U8 ? 768 : 1];
+    if (U8) {
+        for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = ((float)(i & 255) / 255.0f - mean[i >> 8]) / stdv[i >> 8];
+        __syncthreads();
+    }
     float *s_in = sm;                    // [2 parity][3][ITH][PH]
     float *s_conv = sm;                  // [OCB][CONV_PITCH], after the K loop
     const int ph = h / 4, pw = wd / 4, ch = h / 2, cw = wd / 2;
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     const int py0 = tile_y * PTH, px0 = tile_x * PTW;
     const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv row/col of the tile
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input row/col of the patch
-    const float *xi = x + img * 3 * (int64_t)h * wd;
+    const TIN *xi = x + img * 3 * (int64_t)h * wd;
     float x_scale, x_inv;
     range_scales(in_range[img], x_scale, x_inv);
     // per-channel epilogue constants (accumulator scale, norm0 scale and shift) once per workgroup: the epilogue reads them
@@ -129,7 +141,10 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
         const int c = (row >= ITH) + (row >= 2 * ITH), r = row - c * ITH;
         const int yy = iy0 + r;
         vin[t] = 0.0f;
-        if (col_ok && row < 3 * ITH && yy >= 0 && yy < h) vin[t] = xi[((int64_t)c * h + yy) * wd + xx];
+        if (col_ok && row < 3 * ITH && yy >= 0 && yy < h) {
+            if constexpr (U8) vin[t] = s_lut[c * 256 + xi[((int64_t)c * h + yy) * wd + xx]];
+            else vin[t] = xi[((int64_t)c * h + yy) * wd + xx];
+        }
     }
     unsigned *s_w = reinterpret_cast<unsigned *>(s_in);
     // The patch is split into its two fp16 terms HERE, once per input value, and stored as one 32-bit word (hi | lo << 16)
@@ -259,22 +274,40 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const float *__restrict__ x,
     if (out_range) range_publish(out_range, (int)img, vmax, threadIdx.x & 63);
 }
 
-}  // namespace
-
-hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscale, const float *scale, const float *shift,
-                          int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
-                          hipStream_t st) {
+template <typename TIN>
+static hipError_t launch_stem_h2_t(const TIN *x, const uint16_t *w2, const float *oscale, const float *scale, const float *shift,
+                                   int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
+                                   const float *mean, const float *stdv, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (n > 65535 || !in_range || !oscale) return hipErrorInvalidValue;
     const int ph = h / 4, pw = wd / 4;
     const int tiles = ((ph + PTH - 1) / PTH) * ((pw + PTW - 1) / PTW);
     const size_t lds = LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stem_h2, dim3((unsigned)tiles, (unsigned)n, 1), dim3(256), lds, st, x, w2, oscale, scale, shift,
-                       h, wd, y, y_bs, in_range, reinterpret_cast<unsigned *>(out_range));
+    static bool attr_set = false;           // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2<TIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_stem_h2<TIN>, dim3((unsigned)tiles, (unsigned)n, 1), dim3(256), lds, st, x, w2, oscale, scale, shift,
+                       h, wd, y, y_bs, in_range, reinterpret_cast<unsigned *>(out_range), mean, stdv);
     return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscale, const float *scale, const float *shift,
+                          int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
+                          hipStream_t st) {
+    return launch_stem_h2_t<float>(x, w2, oscale, scale, shift, n, h, wd, y, y_bs, in_range, out_range, nullptr, nullptr, st);
+}
+
+hipError_t launch_stem_h2_u8(const uint8_t *x, const float *mean, const float *stdv, const uint16_t *w2, const float *oscale,
+                             const float *scale, const float *shift, int64_t n, int h, int wd, float *y, int64_t y_bs,
+                             const float *in_range, float *out_range, hipStream_t st) {
+    if (!mean || !stdv) return hipErrorInvalidValue;
+    return launch_stem_h2_t<uint8_t>(x, w2, oscale, scale, shift, n, h, wd, y, y_bs, in_range, out_range, mean, stdv, st);
 }
 
 // ---- largest |value| of every image (`per` contiguous fp32 each) into its range: grid (chunks, images) -----------------
@@ -297,11 +330,39 @@ __global__ __launch_bounds__(256) void k_range_absmax(const float *__restrict__ 
 }
 }  // namespace
 
+namespace {
+// the same for raw 8-bit images [n, 3, hw]: the largest |(u / 255 - mean[c]) / std[c]| of every image (the normalisation is
+// monotone per channel, but the table keeps this one pass over the bytes trivially consistent with the stem's)
+__global__ __launch_bounds__(256) void k_range_absmax_u8(const uint8_t *__restrict__ x, int64_t hw, const float *__restrict__ mean,
+                                                         const float *__restrict__ stdv, unsigned *__restrict__ row) {
+    __shared__ float s_lut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = ((float)(i & 255) / 255.0f - mean[i >> 8]) / stdv[i >> 8];
+    __syncthreads();
+    const uint8_t *xi = x + (int64_t)blockIdx.y * 3 * hw;
+    float m = 0.f;
+    for (int c = 0; c < 3; ++c)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+            m = range_max(m, s_lut[c * 256 + xi[c * hw + i]]);
+    range_publish(row, (int)blockIdx.y, m, threadIdx.x & 63);
+}
+}  // namespace
+
+hipError_t launch_range_absmax_u8(const uint8_t *x, int64_t hw, int64_t n, const float *mean, const float *stdv, float *row,
+                                  hipStream_t st) {
+    if (n <= 0 || hw <= 0) return hipSuccess;
+    if (n > 65535 || !mean || !stdv) return hipErrorInvalidValue;
+    const int64_t want = (hw + 255) / 256;
+    const unsigned chunks = (unsigned)(want > 16 ? 16 : want);
+    hipLaunchKernelGGL(k_range_absmax_u8, dim3(chunks, (unsigned)n), dim3(256), 0, st, x, hw, mean, stdv, reinterpret_cast<unsigned *>(row));
+    return hipGetLastError();
+}
+
 hipError_t launch_range_absmax(const float *x, int64_t per, int64_t n, float *row, hipStream_t st) {
     if (n <= 0 || per <= 0) return hipSuccess;
     if (n > 65535) return hipErrorInvalidValue;
-    const int64_t want = (per / 4 + 255) / 256;                 // one 16-byte load per thread
-    const unsigned chunks = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+    // ~16 16-byte loads per thread (64 chunks of one load each took 2.7x the time of the old whole-batch pass)
+    const int64_t want = (per / 4 + 16 * 256 - 1) / (16 * 256);
+    const unsigned chunks = (unsigned)(want < 1 ? 1 : (want > 16 ? 16 : want));
     hipLaunchKernelGGL(k_range_absmax, dim3(chunks, (unsigned)n), dim3(256), 0, st, x, per, reinterpret_cast<unsigned *>(row));
     return hipGetLastError();
 }

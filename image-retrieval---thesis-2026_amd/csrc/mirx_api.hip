@@ -1068,6 +1068,27 @@ int mirx_range_absmax(const float *x, int64_t per_image, int64_t n, float *range
     return MIRX_OK;
 }
 
+int mirx_range_absmax_u8(const uint8_t *x, int64_t hw, int64_t n, const float *mean3, const float *std3, float *range_row,
+                         void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && hw >= 0, "range_absmax_u8: batch must be in [0, 65535]");
+    MIRX_CHECK(n == 0 || hw == 0 || (x && mean3 && std3 && range_row), "range_absmax_u8: null buffer");
+    MIRX_HIP(launch_range_absmax_u8(x, hw, n, mean3, std3, range_row, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_stem_conv7_bn_relu_pool_split2h_u8_into(const uint8_t *x, const float *mean3, const float *std3, const void *w2,
+                                                 const float *oscale, const float *scale, const float *shift, int64_t n, int h,
+                                                 int wd, float *y, int64_t y_batch_stride, const float *in_range,
+                                                 float *out_range_or_null, void *stream) {
+    MIRX_CHECK(x && mean3 && std3 && w2 && oscale && scale && shift && y && in_range && n >= 0 && n <= 65535,
+               "stem_split2h_u8: null argument or batch > 65535");
+    MIRX_CHECK(h >= 8 && wd >= 8 && h % 4 == 0 && wd % 4 == 0, "stem_split2h_u8: H and W must be multiples of 4");
+    MIRX_CHECK(y_batch_stride >= (int64_t)64 * (h / 4) * (wd / 4), "stem_split2h_u8: output batch stride too small");
+    MIRX_HIP(launch_stem_h2_u8(x, mean3, std3, reinterpret_cast<const uint16_t *>(w2), oscale, scale, shift, n, h, wd, y,
+                               y_batch_stride, in_range, out_range_or_null, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, const float *oscale, const float *scale,
                                               const float *shift, int64_t n, int h, int wd, float *y, int64_t y_batch_stride,
                                               const float *in_range, float *out_range_or_null, void *stream) {

@@ -124,14 +124,25 @@ __device__ inline void range_publish(unsigned *__restrict__ row, int img, float 
 }
 
 // lanes may belong to different images (a pixel tile that straddles images; a lane that carries nothing passes a valid
-// image index and vmax = 0): one atomic per wave where the wave is uniform, one per lane otherwise
+// image index and vmax = 0): one atomic per DISTINCT image of the wave -- the images are peeled off one at a time (lowest
+// pending lane's image, masked wave maximum), two or three rounds at most for any tile geometry in this library
 __device__ inline void range_publish_lanes(unsigned *__restrict__ row, int img, float vmax, int lane) {
-    const int first = __builtin_amdgcn_readfirstlane(img);
-    if (__all(img == first)) {                     // wave-uniform branch
-        range_publish(row, first, vmax, lane);
-    } else {
-        const unsigned a = __float_as_uint(vmax);
-        if (a) atomicMax(row + img, a);
+    const unsigned a = __float_as_uint(vmax);
+    bool pending = true;
+    for (;;) {
+        const unsigned long long bm = __ballot(pending);           // wave-uniform
+        if (!bm) break;
+        const int src = __ffsll((long long)bm) - 1;
+        const int cur = __shfl(img, src, 64);
+        const bool mine = pending && img == cur;
+        unsigned m = mine ? a : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == src && m) atomicMax(row + cur, m);
+        pending = pending && !mine;
     }
 }
 

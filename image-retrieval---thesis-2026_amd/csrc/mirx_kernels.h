@@ -36,6 +36,12 @@ hipError_t launch_stem_h2(const float *x, const uint16_t *w2, const float *oscal
                           int64_t n, int h, int wd, float *y, int64_t y_bs, const float *in_range, float *out_range,
                           hipStream_t st);
 hipError_t launch_range_absmax(const float *x, int64_t per_image, int64_t n, float *row, hipStream_t st);
+// raw 8-bit images, ToTensor + Normalize applied while staging (bit-identical to the fp32 path on the normalised tensor)
+hipError_t launch_stem_h2_u8(const uint8_t *x, const float *mean, const float *stdv, const uint16_t *w2, const float *oscale,
+                             const float *scale, const float *shift, int64_t n, int h, int wd, float *y, int64_t y_bs,
+                             const float *in_range, float *out_range, hipStream_t st);
+hipError_t launch_range_absmax_u8(const uint8_t *x, int64_t hw, int64_t n, const float *mean, const float *stdv, float *row,
+                                  hipStream_t st);
 
 // ---- k_conv1x1.hip ----------------------------------------------------------------------
 hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,

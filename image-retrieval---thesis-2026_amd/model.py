@@ -36,6 +36,8 @@ import torch.nn.functional as F
 
 from . import _lib
 
+IMAGENET_MEAN = (0.485, 0.456, 0.406)          # reference test.py:1309-1310
+IMAGENET_STD = (0.229, 0.224, 0.225)
 BLOCK_CONFIG = (6, 12, 24, 16)
 GROWTH = 32
 BN_SIZE = 4
@@ -723,6 +725,10 @@ class DenseNet121(nn.Module):
                                            # (measured faster than the fp32-MFMA kernel on every DenseNet-121 layer)
         self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
+        # raw 8-bit input: forward() also takes uint8 [B, 3, H, W] and applies the reference's ToTensor + Normalize
+        # (test.py:1309-1332) with these constants -- inside the stem kernel at 224 x 224, a quarter of the PCIe / HBM bytes
+        self.register_buffer("input_mean", torch.tensor(IMAGENET_MEAN, dtype=torch.float32), persistent=False)
+        self.register_buffer("input_std", torch.tensor(IMAGENET_STD, dtype=torch.float32), persistent=False)
         self.fused_small_maps = False      # True: 14 x 14 / 7 x 7 dense layers in ONE launch, bottleneck resident in LDS
                                            # (mirx_dense_layer_fused: bit-identical, measured 4-6 % slower so far -- DESIGN 6.3)
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
@@ -817,9 +823,13 @@ class DenseNet121(nn.Module):
         """-> (feature map before norm5 [B,1024,h,w])"""
         f = self.densenet121[0]
         lib = _lib.load()
+        cache = self._cache()
+        if x.dtype == torch.uint8:
+            if self._h2_ok(x):
+                return self._features_h2(x.contiguous(), cache)          # normalised inside the stem kernel
+            x = self.normalize_uint8(x)
         x = x.contiguous().float()
         b, _, h, w = x.shape
-        cache = self._cache()
         if self._h2_ok(x):
             return self._features_h2(x, cache)
         if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
@@ -847,6 +857,13 @@ class DenseNet121(nn.Module):
                 x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer, self.split3_min_cin,
                                       nxt.cout if nxt is not None else None)
         return x
+
+    def normalize_uint8(self, x):
+        """ToTensor + Normalize of the reference (test.py:1309-1332) on a uint8 [B, 3, H, W] batch, the same fp32 operations in
+        the same order (u / 255, - mean, / std): what the stem kernel's table holds."""
+        m = self.input_mean.to(x.device).view(1, 3, 1, 1)
+        s_ = self.input_std.to(x.device).view(1, 3, 1, 1)
+        return (x.float() / 255.0 - m) / s_
 
     def _h2_ok(self, x):
         """The two-fp16-term path covers the geometry of the reference's 224 x 224 evaluation (maps 56 / 28 / 14 / 7)."""
@@ -886,7 +903,8 @@ class DenseNet121(nn.Module):
         f = self.densenet121[0]
         lib = _lib.load()
         h2 = cache.get("h2") or self._prepare_h2(cache)
-        x = x.contiguous().float()
+        u8 = x.dtype == torch.uint8
+        x = x.contiguous() if u8 else x.contiguous().float()
         b = x.shape[0]
         dev = x.device
         st = _stream(dev)
@@ -897,12 +915,23 @@ class DenseNet121(nn.Module):
         ranges = torch.zeros((len(blocks) + nlayers + 1, b), dtype=torch.float32, device=dev)   # one fill per forward
         sc, sh = cache["norm0"]
         xr = ranges[len(blocks) + nlayers]                           # the range of every input image: one pass over them
-        _lib.check(lib.mirx_range_absmax(_ptr(x), x[0].numel(), b, _ptr(xr), st), "mirx_range_absmax")
+        if u8:
+            _lib.check(lib.mirx_range_absmax_u8(_ptr(x), 224 * 224, b, _ptr(self.input_mean), _ptr(self.input_std), _ptr(xr), st),
+                       "mirx_range_absmax_u8")
+        else:
+            _lib.check(lib.mirx_range_absmax(_ptr(x), x[0].numel(), b, _ptr(xr), st), "mirx_range_absmax")
         w2, osc = cache["conv0_w2"]
         sides = [56 >> k for k in range(len(blocks))]
         rows = [len(blocks) + sum(len(m) for _, m in blocks[:k]) for k in range(len(blocks))]
 
         def stem(xs, dst):
+            if u8:
+                _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split2h_u8_into(_ptr(xs), _ptr(self.input_mean), _ptr(self.input_std),
+                                                                            _ptr(w2), _ptr(osc), _ptr(sc), _ptr(sh), xs.shape[0],
+                                                                            224, 224, _ptr(dst), dst.shape[1] * dst.shape[2],
+                                                                            _ptr(xr), _ptr(ranges[0]), st),
+                           "mirx_stem_split2h_u8_into")
+                return
             _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split2h_into(_ptr(xs), _ptr(w2), _ptr(osc), _ptr(sc), _ptr(sh),
                                                                      xs.shape[0], 224, 224, _ptr(dst),
                                                                      dst.shape[1] * dst.shape[2], _ptr(xr), _ptr(ranges[0]), st),
@@ -952,7 +981,7 @@ class DenseNet121(nn.Module):
                 if plain_head:
                     return x                       # already unit-norm (model.py:83)
         else:
-            x = self.forward_eager(x)
+            x = self.forward_eager(self.normalize_uint8(x) if x.dtype == torch.uint8 else x)
         if self.fc:
             x = self.fc(x)
         if self.classification_head is not None:

@@ -263,6 +263,17 @@ int mirx_dense_layer_fused(float *buf, int64_t batch_stride, int64_t plane_strid
  * block 1's buffer: no copy); in_range = range row of x, out_range_or_null = range row of y.  n <= 65535.
  * (reference: conv0 / norm0 / relu0 / pool0 of torchvision densenet121, model.py:53-60) */
 int mirx_range_absmax(const float *x, int64_t per_image, int64_t n, float *range_row, void *stream);
+/* The same two entry points for RAW 8-bit images x = device uint8 [n, 3, h, w] (hw = h * w): the reference's ToTensor +
+ * Normalize (x = u / 255, then (x - mean3[c]) / std3[c] in fp32: test.py:1309-1332) is applied while the stem stages its input
+ * patch (and by the range pass), through a 3 x 256 table built with exactly those operations -- the embeddings are
+ * bit-identical to feeding the normalised fp32 tensor, at a quarter of the input bytes over PCIe and out of HBM.
+ * mean3 / std3 = device fp32 [3]. */
+int mirx_range_absmax_u8(const uint8_t *x, int64_t hw, int64_t n, const float *mean3, const float *std3, float *range_row,
+                         void *stream);
+int mirx_stem_conv7_bn_relu_pool_split2h_u8_into(const uint8_t *x, const float *mean3, const float *std3, const void *w2,
+                                                 const float *oscale, const float *scale, const float *shift, int64_t n, int h,
+                                                 int w, float *y, int64_t y_batch_stride, const float *in_range,
+                                                 float *out_range_or_null, void *stream);
 int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, const float *oscale, const float *scale,
                                               const float *shift, int64_t n, int h, int w, float *y, int64_t y_batch_stride,
                                               const float *in_range, float *out_range_or_null, void *stream);

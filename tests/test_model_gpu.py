@@ -666,3 +666,29 @@ def test_fused_and_two_launch_small_maps_give_the_same_embeddings(model_and_sd):
         finally:
             m.fused_small_maps = False
     assert torch.equal(fused, two)
+
+
+@pytest.mark.gpu
+def test_uint8_images_embed_bit_identically_to_the_normalised_tensor(model_and_sd):
+    """forward() on raw uint8 [B, 3, 224, 224] (ToTensor + Normalize of test.py:1309-1332 applied inside the stem kernel
+    through a 3 x 256 table) against forward() on the tensor the reference's CPU transform produces (u / 255, - mean, / std in
+    fp32): the same bits, per-image ranges included; the CPU restatement is met to 1e-5."""
+    m, sd = model_and_sd
+    g = torch.Generator().manual_seed(31)
+    u8 = torch.randint(0, 256, (6, 3, 224, 224), generator=g, dtype=torch.uint8)
+    u8[3] = torch.randint(100, 140, (3, 224, 224), generator=g, dtype=torch.uint8)      # a flat image: its own, smaller range
+    u8[4, :, :, :] = 0
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    xf = (u8.float() / 255.0 - mean) / std                     # torchvision ToTensor + Normalize, on the CPU like the reference
+    assert torch.equal(m.normalize_uint8(u8), xf)              # CPU tensor in, CPU ops
+    with torch.no_grad():
+        e_u8 = m(u8.cuda()).cpu()
+        e_f = m(xf.cuda()).cpu()
+        ref = OD.embed(xf, sd)
+    assert torch.equal(e_u8, e_f)
+    assert float((e_u8 - ref).abs().max()) <= 1e-5
+    with torch.no_grad():                                      # other sizes: normalised by torch ops, then the legacy path
+        small = m(u8[:2, :, :160, :192].contiguous().cuda()).cpu()
+        want = m(xf[:2, :, :160, :192].contiguous().cuda()).cpu()
+    assert float((small - want).abs().max()) <= 1e-6

@@ -42,13 +42,14 @@ def dominant(tag):
 
 
 def main():
-    out = {"_method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = 2 * FETCH_SIZE_KB * 1024 + "
+    out = {"_batches": "passes run at the batch sizes bench.py times (DenseNet 2048 per stream, extras 64 / 32 / 16)",
+           "_method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = 2 * FETCH_SIZE_KB * 1024 + "
                       "WRITE_SIZE_KB * 1024 (gfx950: FETCH_SIZE counts half the bytes of wide coalesced loads)"}
     b, n, fe, wr = family("gemm", r"k_gemm16<0, false>")
     if n:
         out["gemm_1Mx1024_q4096"] = {"bytes_per_launch": b / n, "launches": n, "fetch_bytes_raw": fe / n, "write_bytes": wr / n,
                                       "algorithmic_bytes": 1_000_000 * 1024 * 2 + 4096 * 1024 * 2}
-    forwards, batch = 2, 256                       # bench_embed --iters 1 --warmup 1
+    forwards, batch = 2, 2048                      # bench_embed --batch 2048 --iters 1 --warmup 1: the bench's forward per stream
     b, n, fe, wr = family("densenet", r"k_conv1x1_h2")
     if n:
         out["densenet121_conv1x1"] = {"bytes_per_image": b / (forwards * batch), "launches_per_forward": n // forwards,
@@ -60,12 +61,12 @@ def main():
     if n:
         out["densenet121_forward"] = {"bytes_per_image": tot / (forwards * batch), "dominant_kernel": k,
                                       "algorithmic_bytes_per_image_fp32": 95.2e6}
-    for tag, name, bs in (("convnextv2", "convnextv2_base_384", 16), ("dinov2", "dinov2_vitb14_518", 8), ("medsiglip", "medsiglip_448", 4)):
+    for tag, name, bs in (("convnextv2", "convnextv2_base_384", 64), ("dinov2", "dinov2_vitb14_518", 32), ("medsiglip", "medsiglip_448", 16)):
         try:
             k, tot = dominant(tag)
         except ValueError:
             continue
-        out[name] = {"bytes_per_forward": tot / 2, "bytes_per_image": tot / (2 * bs), "batch": bs, "dominant_kernel": k}
+        out[name] = {"bytes_per_forward": tot / 2, "bytes_per_image": tot / (2 * bs), "batch": bs, "dominant_kernel": k}   # the batch bench.py times
     print(json.dumps(out, indent=1))
 
 
