@@ -28,50 +28,47 @@ COVIDX_LABEL_TO_TEXT = {
 }
 
 
-def _features(out, name):
-    """transformers >= 5 returns an output object from get_*_features, older versions a tensor."""
-    if torch.is_tensor(out):
-        return out
-    return getattr(out, "pooler_output", None) if getattr(out, name, None) is None else getattr(out, name)
+def _encode(model, kind, **inputs):
+    """Unit-norm features of one tower.  kind = "text" | "image"; `inputs` are that tower's keyword tensors.  Models with the
+    SiglipModel surface answer through get_<kind>_features (a tensor, or -- transformers >= 5 -- an output object whose
+    <kind>_embeds / pooler_output holds it); anything else is called whole and its <kind>_embeds taken (eval_medsiglip.py:174-184,
+    205-211 accept both)."""
+    getter = getattr(model, f"get_{kind}_features", None)
+    out = getter(**inputs) if getter is not None else model(**inputs)
+    if not torch.is_tensor(out):
+        emb = getattr(out, f"{kind}_embeds", None)
+        out = emb if emb is not None else out.pooler_output
+    return F.normalize(out, dim=-1)
 
 
 @torch.no_grad()
 def get_text_features(model, processor, device, prompts, max_text_length):
-    text_inputs = processor.tokenizer(prompts, max_length=max_text_length, padding="max_length", truncation=True,
-                                      return_attention_mask=True, return_tensors="pt").to(device)
-    if hasattr(model, "get_text_features"):
-        feats = _features(model.get_text_features(input_ids=text_inputs["input_ids"],
-                                                  attention_mask=text_inputs["attention_mask"]), "text_embeds")
-    else:
-        feats = model(input_ids=text_inputs["input_ids"], attention_mask=text_inputs["attention_mask"]).text_embeds
-    return F.normalize(feats, dim=-1)
+    """eval_medsiglip.py:163-186: tokenise to a fixed length, encode, unit-normalise."""
+    tok = processor.tokenizer(prompts, max_length=max_text_length, padding="max_length", truncation=True,
+                              return_attention_mask=True, return_tensors="pt").to(device)
+    return _encode(model, "text", input_ids=tok["input_ids"], attention_mask=tok["attention_mask"])
 
 
 @torch.no_grad()
 def evaluate(model, processor, loader, device, args, label_to_text=None):
     model.eval()
     label_to_text = label_to_text or COVIDX_LABEL_TO_TEXT
-    class_prompts = [label_to_text[i] for i in sorted(label_to_text)]
-    text_features = get_text_features(model, processor, device, class_prompts, args.max_text_length)
-    logit_scale = model.logit_scale.exp() if hasattr(model, "logit_scale") else torch.tensor(100.0, device=device)
+    text_features = get_text_features(model, processor, device, [label_to_text[i] for i in sorted(label_to_text)],
+                                      args.max_text_length)
 
-    preds, labs, embeds = [], [], []
-    for batch_idx, batch in enumerate(loader):
-        pixel_values = batch["pixel_values"].to(device)
-        if hasattr(model, "get_image_features"):
-            image_features = _features(model.get_image_features(pixel_values=pixel_values), "image_embeds")
-        else:
-            image_features = model(pixel_values=pixel_values).image_embeds
-        image_features = F.normalize(image_features, dim=-1)
-        logits = logit_scale * image_features @ text_features.t()
-        preds.append(torch.argmax(logits, dim=-1))
+    # image tower over the loader: features and labels stay on the device; the zero-shot decision is ONE product over all of
+    # them afterwards (the reference decides batch by batch and ships every batch to the host: eval_medsiglip.py:201-219)
+    feats, labs = [], []
+    for done, batch in enumerate(loader, start=1):
+        feats.append(_encode(model, "image", pixel_values=batch["pixel_values"].to(device)))
         labs.append(batch["labels"].to(device))
-        embeds.append(image_features)                       # stays on the device (the reference moves it to the host)
-        if (batch_idx + 1) % 10 == 0:
-            print(f"Processed {(batch_idx + 1) * args.eval_batch_size} images...")
+        if done % 10 == 0:
+            print(f"Processed {done * args.eval_batch_size} images...")
+    embeds = torch.cat(feats, dim=0).float()
     labels = torch.cat(labs).long()
-    embeds = torch.cat(embeds, dim=0).float()
-    all_predictions, all_labels = torch.cat(preds).cpu().numpy(), labels.cpu().numpy()
+    scale = model.logit_scale.exp() if hasattr(model, "logit_scale") else torch.tensor(100.0, device=device)
+    all_predictions = torch.argmax(scale * embeds @ text_features.float().t(), dim=-1).cpu().numpy()
+    all_labels = labels.cpu().numpy()
 
     p, r, f, _ = _prf(all_labels, all_predictions)          # sklearn macro averages, zero_division=0
     zs = {"accuracy": float(np.mean(all_predictions == all_labels) * 100.0), "precision_macro": float(p.mean() * 100.0),

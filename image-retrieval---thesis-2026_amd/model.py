@@ -27,6 +27,7 @@ MI355X path (CUDA tensors, eval mode):
 unless a local state dict is given via ``weights=``.
 """
 import ctypes
+import dataclasses
 import math
 from collections import OrderedDict
 
@@ -82,6 +83,63 @@ class _DenseBlock(nn.ModuleDict):
         return buf
 
 
+@dataclasses.dataclass(frozen=True)
+class KernelConfig:
+    """Which kernel family each piece of the inference path runs on.  FROZEN: a model holds one instance (`model.kernel_config`,
+    every submodule carries a reference) and `model.configure(name=value, ..)` swaps in a modified copy -- no module-level
+    switch, nothing another thread or another model instance can observe half-changed.  The defaults are the shipped path; the
+    rest are measured alternatives kept for A/B runs and for inputs the default path does not cover."""
+    densenet_two_fp16: bool = True          # DenseNet at 224 x 224: every conv on two fp16 terms, per-image value ranges
+    plane_stride: tuple = ()                # ((side, floats between channel planes), ..): padded block buffers (measured: no gain)
+    fused_small_maps: bool = False          # 14 x 14 / 7 x 7 dense layers in ONE launch (mirx_dense_layer_fused; slower so far)
+    hip_stem: bool = True                   # legacy (not 224 x 224) path: the stem kernel (False: torch ops)
+    stem_three_bf16: bool = True            #   .. on three bf16 terms (False: fp32 MFMAs)
+    hip_conv1x1: bool = True                #   fused 1x1 convs (False: rocBLAS via torch)
+    conv1x1_three_bf16_min_cin: int = 0     #   1x1 convs with at least this many input channels on three bf16 terms
+    hip_conv3x3: bool = True                #   own 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
+    conv3x3_legacy: tuple = ((56, "wino"), (28, "wino3"), (14, "direct3"), (7, "wino"))
+    linear_three_bf16: bool = True          # token-major Linears on the MFMA kernels at all (False: rocBLAS fp32)
+    linear_two_fp16: bool = True            #   .. on two fp16 terms where the input has a provable bound (LayerNorm outputs)
+    attention_three_bf16: bool = True       # flash attention on three bf16 terms (False: fp32 MFMAs)
+    attention_two_fp16: bool = True         #   .. on two fp16 terms where q / k / v have provable bounds
+    grn_scale_kernel: bool = True           # ConvNeXtV2: GRN scale vector + its maximum in one launch (False: five ATen launches)
+
+
+DEFAULT_CONFIG = KernelConfig()
+
+
+def _cfg(mod):
+    """The kernel configuration a module runs under (its model's, or the defaults for a module used on its own)."""
+    return getattr(mod, "_mirx_cfg", DEFAULT_CONFIG)
+
+
+def set_kernel_config(module, cfg):
+    """Put every submodule of `module` under `cfg` (what model.configure() does; also for a block used on its own)."""
+    assert isinstance(cfg, KernelConfig)
+    for m in module.modules():
+        m.__dict__["_mirx_cfg"] = cfg
+
+
+class _Configurable:
+    """Mixin of the top-level models: `kernel_config` and `configure(**changes)`."""
+
+    def _init_config(self):
+        set_kernel_config(self, DEFAULT_CONFIG)
+
+    def _set_config(self, cfg):
+        set_kernel_config(self, cfg)
+
+    @property
+    def kernel_config(self):
+        return _cfg(self)
+
+    def configure(self, **changes):
+        """Swap in a copy of the configuration with `changes` applied; returns the previous configuration (to restore)."""
+        old = _cfg(self)
+        self._set_config(dataclasses.replace(old, **changes))
+        return old
+
+
 def _timer_start(timer):
     """Optional per-launch timing of the fused conv kernel (bench.py's calibration pass)."""
     if timer is None:
@@ -107,8 +165,7 @@ def _fused_bn_relu(lib, buf, c, scale, shift):
     return out
 
 
-def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hip_conv3x3=True,
-                       split3_min_cin=0):
+def _dense_block_fused(block, x, cache, cfg, timer=None):
     """Inference path of one dense block (CUDA, eval):
        per layer: [HIP] norm1+relu1 over the buffer prefix -> conv1 (1x1, norm2's scale folded into
        its weights) -> [HIP] norm2 shift + relu2 in place -> conv2 (3x3) -> 32 new channels copied
@@ -125,11 +182,11 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
     c = block.cin
     for name, layer in block.items():
         sc1, sh1, w1, b1, ones, w1t, u3, w3 = cache[name]
-        if use_hip_conv1x1:
+        if cfg.hip_conv1x1:
             # norm1 + relu1 + conv1 + norm2 + relu2 in ONE fp32-MFMA pass over the buffer prefix
             y = torch.empty((b, w1t.shape[1], h, w), dtype=torch.float32, device=x.device)
             ev = _timer_start(timer)
-            if c >= split3_min_cin:
+            if c >= cfg.conv1x1_three_bf16_min_cin:
                 # three-bf16-term MFMA formulation (fp32-grade, faster than the fp32-MFMA kernel on every layer)
                 _lib.check(lib.mirx_conv1x1_bn_relu_split3(_ptr(buf), block.cout * h * w, c, _ptr(sc1), _ptr(sh1),
                                                            _ptr(w3), _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y),
@@ -140,13 +197,13 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
                                                     _ptr(b1), b, h * w, w1t.shape[1], 1, _ptr(y), _stream(x.device)),
                            "mirx_conv1x1_bn_relu")
             _timer_stop(timer, ev, 2.0 * b * h * w * c * w1t.shape[1])
-            if use_hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
+            if cfg.hip_conv3x3 and h == w and h in (56, 28, 14, 7) and b <= 65535:
                 # written straight into this layer's slice of the buffer.  Per map side (measured, 1024 images):
                 # 56: Winograd F(2x2,3x3) on fp32 MFMAs (1.37 ms; the bf16 variants are operand-delivery bound there);
                 # 28: Winograd on three-term bf16 MFMAs (0.32 vs 0.35 ms); 14: direct implicit GEMM on three-term
                 # bf16 MFMAs (0.078 vs 0.090 / 0.097 ms); 7: Winograd fp32, two images per workgroup
                 dst = ctypes.c_void_p(buf.data_ptr() + 4 * c * h * w)
-                kind = CONV3X3_KERNEL.get(h, "wino")
+                kind = dict(cfg.conv3x3_legacy).get(h, "wino")
                 if kind == "direct3":
                     _lib.check(lib.mirx_conv3x3_direct_split3_nchw(_ptr(y), _ptr(u3[2]), b, h, dst, block.cout * h * w,
                                                                    _stream(x.device)), "mirx_conv3x3_direct_split3_nchw")
@@ -173,7 +230,7 @@ def _dense_block_fused(block, x, cache, use_hip_conv1x1=True, timer=None, use_hi
     return buf
 
 
-def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_min_cin=0, next_channels=None):
+def _transition_fused(tr, buf, cache, cfg, timer=None, next_channels=None):
     """[HIP] norm+relu+avgpool2x2 in one pass, then the 1x1 conv on the POOLED map (the conv and
     the average pool are both linear and commute; 4x fewer pixels go through the conv)."""
     lib = _lib.load()
@@ -185,9 +242,9 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
     pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
     _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * h * w, _ptr(sc), _ptr(sh), b, c, h, w, _ptr(pooled), 0,
                                          _stream(buf.device)), "mirx_bn_relu_avgpool2")
-    if use_hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
+    if cfg.hip_conv1x1 and wt.shape[1] % 128 == 0 and c % 32 == 0:
         ev = _timer_start(timer)
-        if c >= split3_min_cin:
+        if c >= cfg.conv1x1_three_bf16_min_cin:
             # written straight into the channel prefix of the NEXT dense block's buffer when its width is known
             ctot = next_channels if next_channels else wt.shape[1]
             out = torch.empty((b, ctot, h // 2, w // 2), dtype=torch.float32, device=buf.device)
@@ -207,18 +264,15 @@ def _transition_fused(tr, buf, cache, use_hip_conv1x1=True, timer=None, split3_m
     return F.conv2d(pooled, tr.conv.weight)
 
 
-PLANE_STRIDE_H2 = {}       # map side -> floats between channel planes of that block's buffer (absent: packed, side^2)
-
-
-def _plane_stride(side):
-    """Floats between consecutive channel planes of a dense block's buffer on the two-fp16-term path (terms kernels only).
+def _plane_stride(side, cfg=DEFAULT_CONFIG):
+    """Floats between consecutive channel planes of a dense block's buffer on the two-fp16-term path.
     784-byte (14 x 14) and 3136-byte (28 x 28) planes start at every 16-byte offset of a 128-byte line, so a wave's 256-byte
     load straddles three lines instead of two; in isolation the block-3 conv1x1 layers run at 4.1 instead of 3.5 TB/s on
     line-aligned planes (stride 224).  In the whole forward the padded layouts measured 1 % SLOWER (42.4 vs 42.8 k img/s,
     same box, B = 4096), so the default stays packed; the kernels and the ABI take the stride
-    (tools/bench_embed.py --plane-stride 14:224)."""
+    (KernelConfig.plane_stride, tools/bench_embed.py --plane-stride 14:224)."""
     hw = side * side
-    ps = PLANE_STRIDE_H2.get(side, hw)
+    ps = dict(cfg.plane_stride).get(side, hw)
     assert ps == hw or (ps > hw and ps % 4 == 0)
     return ps
 
@@ -467,17 +521,8 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-CONV3X3_KERNEL = {56: "wino", 28: "wino3", 14: "direct3", 7: "wino"}   # dense-layer 3x3 conv kernel per map side
-# Two-fp16-term DenseNet path (224 x 224 inputs): value ranges travel with the activations, one float per image and buffer
-# (include/mirx.h, mirx_conv1x1_bn_relu_split2h)
-SPLIT2H_DENSENET = True
-SPLIT3_STEM = True       # DenseNet stem conv on three-term bf16 MFMAs (False: fp32 MFMAs)
-SPLIT3_ATTENTION = True  # attention with both GEMMs on three-term bf16 MFMAs (False: fp32 MFMAs)
-SPLIT3_LINEAR = True     # token-major Linear layers on the three-term bf16 MFMA kernel (False: rocBLAS fp32)
-
-
 def _linear_s3_ok(mod, x):
-    return (SPLIT3_LINEAR and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+    return (_cfg(mod).linear_three_bf16 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
             and mod.in_features % 16 == 0)
 
 
@@ -490,11 +535,6 @@ def _linear_w3(mod):
         cached = (key, _split3_weights(w.detach()))
         mod._mirx_w3 = cached
     return cached[1]
-
-
-SPLIT2H_LINEAR = True    # Linears fed by a LayerNorm: two fp16 terms per operand (3 MFMAs per product) instead of three bf16
-GRN_SCALE_KERNEL = True    # ConvNeXtV2: the GRN scale vector and its maximum in one HIP launch (False: five ATen launches)
-SPLIT2H_ATTENTION = True   # flash attention on two fp16 terms where q / k / v have provable bounds (else three bf16 terms)
 
 
 def _linear_h2_weights(mod):
@@ -562,7 +602,7 @@ def _linear_out_bound(ln, lin, rows=None):
 
 
 def _linear_h2_ok(mod, x, bound):
-    return (SPLIT2H_LINEAR and _linear_s3_ok(mod, x) and math.isfinite(bound) and 0.0 < bound < 3.0e4)
+    return (_cfg(mod).linear_two_fp16 and _linear_s3_ok(mod, x) and math.isfinite(bound) and 0.0 < bound < 3.0e4)
 
 
 def _linear_h2(mod, x, bound, act=0, res=None, gamma=None, out=None):
@@ -703,7 +743,7 @@ def _conv_patch_tokens(conv, x, ln2d=None, nchw_out=False):
     return _linear_s3(pl, rows)
 
 
-class DenseNet121(nn.Module):
+class DenseNet121(_Configurable, nn.Module):
     """Reference model.py:42-84, MI355X-native inference path."""
 
     def __init__(self, pretrained=False, embedding_dim=None, num_labels=None, weights=None):
@@ -719,19 +759,13 @@ class DenseNet121(nn.Module):
         self.fc = nn.Linear(in_features, embedding_dim) if embedding_dim else None
         out_features = embedding_dim if embedding_dim else in_features
         self.classification_head = nn.Linear(out_features, num_labels) if num_labels else None
-        self.use_hip_stem = True
-        self.use_hip_conv1x1 = True        # fused fp32-MFMA 1x1 convs (False: rocBLAS via torch)
-        self.split3_min_cin = 0            # 1x1 convs with at least this many input channels use the 3-term bf16 kernel
-                                           # (measured faster than the fp32-MFMA kernel on every DenseNet-121 layer)
-        self.use_hip_conv3x3 = True        # Winograd fp32-MFMA 3x3 convs on the 56 / 28 / 14 / 7 maps (False: MIOpen)
         self.conv1x1_timer = None          # list -> (start event, stop event, FLOP) per fused conv launch
         # raw 8-bit input: forward() also takes uint8 [B, 3, H, W] and applies the reference's ToTensor + Normalize
         # (test.py:1309-1332) with these constants -- inside the stem kernel at 224 x 224, a quarter of the PCIe / HBM bytes
         self.register_buffer("input_mean", torch.tensor(IMAGENET_MEAN, dtype=torch.float32), persistent=False)
         self.register_buffer("input_std", torch.tensor(IMAGENET_STD, dtype=torch.float32), persistent=False)
-        self.fused_small_maps = False      # True: 14 x 14 / 7 x 7 dense layers in ONE launch, bottleneck resident in LDS
-                                           # (mirx_dense_layer_fused: bit-identical, measured 4-6 % slower so far -- DESIGN 6.3)
         self._infer_cache = None           # folded BatchNorm parameters of the inference path
+        self._init_config()
         if weights is not None:
             sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
             for key in ("state-dict", "state_dict"):      # wrappers test.py:1273-1276 accepts
@@ -832,10 +866,11 @@ class DenseNet121(nn.Module):
         b, _, h, w = x.shape
         if self._h2_ok(x):
             return self._features_h2(x, cache)
-        if self.use_hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
+        cfg = _cfg(self)
+        if cfg.hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
             sc, sh = cache["norm0"]
             y = torch.empty((b, INIT_FEATURES, h // 4, w // 4), dtype=torch.float32, device=x.device)
-            if SPLIT3_STEM and b <= 65535:
+            if cfg.stem_three_bf16 and b <= 65535:
                 if "conv0_w3" not in cache:
                     cache["conv0_w3"] = _stem_weights_split3(f.conv0.weight)
                 _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3(_ptr(x), _ptr(cache["conv0_w3"]), _ptr(sc), _ptr(sh),
@@ -850,12 +885,10 @@ class DenseNet121(nn.Module):
         children = list(f.named_children())
         for i, (name, m) in enumerate(children):
             if name.startswith("denseblock"):
-                x = _dense_block_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer,
-                                       self.use_hip_conv3x3, self.split3_min_cin)
+                x = _dense_block_fused(m, x, cache[name], cfg, self.conv1x1_timer)
             elif name.startswith("transition"):
                 nxt = children[i + 1][1] if i + 1 < len(children) and children[i + 1][0].startswith("denseblock") else None
-                x = _transition_fused(m, x, cache[name], self.use_hip_conv1x1, self.conv1x1_timer, self.split3_min_cin,
-                                      nxt.cout if nxt is not None else None)
+                x = _transition_fused(m, x, cache[name], cfg, self.conv1x1_timer, nxt.cout if nxt is not None else None)
         return x
 
     def normalize_uint8(self, x):
@@ -867,7 +900,8 @@ class DenseNet121(nn.Module):
 
     def _h2_ok(self, x):
         """The two-fp16-term path covers the geometry of the reference's 224 x 224 evaluation (maps 56 / 28 / 14 / 7)."""
-        return (SPLIT2H_DENSENET and self.use_hip_stem and self.use_hip_conv1x1 and self.use_hip_conv3x3 and SPLIT3_STEM
+        cfg = _cfg(self)
+        return (cfg.densenet_two_fp16 and cfg.hip_stem and cfg.hip_conv1x1 and cfg.hip_conv3x3 and cfg.stem_three_bf16
                 and x.shape[-1] == 224 and x.shape[-2] == 224 and 0 < x.shape[0] <= 65535)
 
     def _prepare_h2(self, cache):
@@ -903,6 +937,7 @@ class DenseNet121(nn.Module):
         f = self.densenet121[0]
         lib = _lib.load()
         h2 = cache.get("h2") or self._prepare_h2(cache)
+        cfg = _cfg(self)
         u8 = x.dtype == torch.uint8
         x = x.contiguous() if u8 else x.contiguous().float()
         b = x.shape[0]
@@ -940,12 +975,12 @@ class DenseNet121(nn.Module):
         def block_and_transition(k, bk, nxt):
             name, blk = blocks[k]
             _dense_block_h2(blk, bk, sides[k], ranges[k], h2[name], ranges[rows[k]:rows[k] + len(blk)], self.conv1x1_timer,
-                            self.fused_small_maps)
+                            cfg.fused_small_maps)
             if nxt is not None:
                 _transition_h2(bk, sides[k], h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
 
         def new_buf(k, n):
-            return torch.empty((n, blocks[k][1].cout, _plane_stride(sides[k])), dtype=torch.float32, device=dev)
+            return torch.empty((n, blocks[k][1].cout, _plane_stride(sides[k], cfg)), dtype=torch.float32, device=dev)
 
         buf = new_buf(0, b)
         stem(x, buf)
@@ -1086,7 +1121,7 @@ class _CnxBlock(nn.Module):
             with torch.cuda.device(x.device):
                 st = _stream(x.device)
                 _lib.check(lib.mirx_grn_norm_nhwc(_ptr(hid), b, h * w, c4, _ptr(gx), st), "mirx_grn_norm_nhwc")
-                if GRN_SCALE_KERNEL:
+                if _cfg(self).grn_scale_kernel:
                     scale = torch.empty_like(gx)
                     smax = torch.zeros(1, dtype=torch.float32, device=x.device)
                     _lib.check(lib.mirx_grn_scale(_ptr(gx), _ptr(mlp.grn.weight.detach().reshape(-1).contiguous()), b, c4, 1e-6,
@@ -1127,7 +1162,7 @@ class _CnxStage(nn.Module):
     def forward(self, x):
         ds = self.downsample
         if (isinstance(ds, nn.Sequential) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and x.shape[0] <= 65535 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and SPLIT3_LINEAR):
+                and x.shape[0] <= 65535 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and _cfg(self).linear_three_bf16):
             # MI355X path: LayerNorm2d + the NCHW -> patch-row gather in one HIP pass, the 2x2/2 conv as an MFMA Linear
             # that writes the next stage's NCHW map
             x = _conv_patch_tokens(ds[1], x, ln2d=ds[0], nchw_out=True)
@@ -1166,7 +1201,7 @@ class _ConvNeXtV2Backbone(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def _stem(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and SPLIT3_LINEAR
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and _cfg(self).linear_three_bf16
                 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0):
             b, _, h, w = x.shape
             tok = _conv_patch_tokens(self.stem[0], x)                          # [b * h/4 * w/4, 128]
@@ -1177,7 +1212,7 @@ class _ConvNeXtV2Backbone(nn.Module):
         return self.head(self.stages(self._stem(x)))
 
 
-class ConvNeXtV2(nn.Module):
+class ConvNeXtV2(_Configurable, nn.Module):
     """Reference model.py:87-117: `convnext` backbone, optional `fc`, unit-norm output."""
 
     def __init__(self, pretrained=False, embedding_dim=None, weights=None):
@@ -1239,7 +1274,7 @@ class _VitAttention(nn.Module):
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 lib = _lib.load()
-                att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                att = lib.mirx_attention_qkv_f32_split3 if _cfg(self).attention_three_bf16 else lib.mirx_attention_qkv_f32
                 _lib.check(att(_ptr(qkv), b, n, self.num_heads, dh, float(dh) ** -0.5, _ptr(a), _stream(x.device)),
                            "mirx_attention_qkv_f32")
             return self.proj(a)
@@ -1286,12 +1321,12 @@ class _VitBlock(nn.Module):
                 lib = _lib.load()
                 bqk = _linear_out_bound(self.norm1, at.qkv, slice(0, 2 * c))
                 bv = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
-                if SPLIT2H_ATTENTION and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+                if _cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
                     # q, k, v are outputs of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
                     _lib.check(lib.mirx_attention_qkv_f32_split2h(_ptr(qkv), b, n, at.num_heads, 64, 0.125, bqk, bv, _ptr(a),
                                                                   _stream(x.device)), "mirx_attention_qkv_f32_split2h")
                 else:
-                    att = lib.mirx_attention_qkv_f32_split3 if SPLIT3_ATTENTION else lib.mirx_attention_qkv_f32
+                    att = lib.mirx_attention_qkv_f32_split3 if _cfg(self).attention_three_bf16 else lib.mirx_attention_qkv_f32
                     _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
                                "mirx_attention_qkv_f32")
             # attention output = softmax-weighted average of V rows: bounded like the V part of the qkv projection
@@ -1315,7 +1350,7 @@ class _PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and SPLIT3_LINEAR:
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[0] <= 65535 and _cfg(self).linear_three_bf16:
             # MI355X path: the stride-14 patch convolution as patch gather + MFMA Linear (no library convolution)
             return _conv_patch_tokens(self.proj, x).view(x.shape[0], -1, self.proj.out_channels)
         return self.proj(x).flatten(2).transpose(1, 2)
@@ -1367,7 +1402,7 @@ def _normalize_rows(x):
     return F.normalize(x, dim=1)
 
 
-class DinoV2(nn.Module):
+class DinoV2(_Configurable, nn.Module):
     """Reference model.py:448-494 (`backbone`, `fc`; the last `unfreeze_blocks` blocks + final norm
     trainable, the rest frozen)."""
 
@@ -1404,7 +1439,7 @@ class DinoV2(nn.Module):
         return _normalize_rows(x)
 
 
-class DINOv2MultiLabelRetrievalModel(nn.Module):
+class DINOv2MultiLabelRetrievalModel(_Configurable, nn.Module):
     """Reference nih_multilabel_retrieval.py:170-221: dict with cls_embedding / projection /
     embedding (unit norm, 256-d) / logits."""
 
@@ -1425,7 +1460,7 @@ class DINOv2MultiLabelRetrievalModel(nn.Module):
                 "embedding": _normalize_rows(projection), "logits": self.classification_head(projection)}
 
 
-class ConvNeXtV2MultiLabelRetrievalModel(nn.Module):
+class ConvNeXtV2MultiLabelRetrievalModel(_Configurable, nn.Module):
     """Reference nih_multilabel_retrieval.py:224-257."""
 
     def __init__(self, num_labels=14, backbone_name="convnextv2_base.fcmae_ft_in22k_in1k_384", pretrained=False):
@@ -1450,7 +1485,7 @@ class ConvNeXtV2MultiLabelRetrievalModel(nn.Module):
 # transformers class is built from a LOCAL config, so `backbone.*` / `projection.*` checkpoints
 # load unchanged and nothing is fetched.
 # =================================================================================================
-class MedSigLIP(nn.Module):
+class MedSigLIP(_Configurable, nn.Module):
     """Reference model.py:536-634: `backbone` (the SigLIP vision tower), `projection`, unit-norm output."""
 
     def __init__(self, model_name="google/medsiglip-448", embed_dim=512, unfreeze_layers=2, vision_config=None,

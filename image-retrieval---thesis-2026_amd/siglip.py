@@ -136,7 +136,7 @@ class _EncoderLayer(nn.Module):
             bqk = max(_m._linear_out_bound(self.layer_norm1, sa.q_proj), _m._linear_out_bound(self.layer_norm1, sa.k_proj))
             bv = _m._linear_out_bound(self.layer_norm1, sa.v_proj)
             flash = key_mask is None and n >= 32 and sa.head_dim in (32, 64, 72, 96) and b <= 65535
-            if flash and _m.SPLIT2H_ATTENTION and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+            if flash and _m._cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
                 # q, k, v come out of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
                 _lib.check(lib.mirx_attention_qkv_f32_split2h(_m._ptr(qkv), b, n, sa.num_heads, sa.head_dim, float(sa.scale),
                                                               bqk, bv, _m._ptr(ctx), st), "mirx_attention_qkv_f32_split2h")

@@ -2,6 +2,7 @@
 a float64 restatement of  y = epi(x W^T + b).  Tolerance: 3e-6 of the largest |y| (the dropped cross
 terms are <= 3 * 2^-24 per product; accumulation is fp32) -- the class of an fp32 GEMM."""
 import ctypes
+import dataclasses
 import math
 
 import pytest
@@ -77,11 +78,11 @@ def test_vit_block_split3_matches_rocblas_path():
             p.normal_(std=0.1)
         x = torch.randn(3, 257, 768, device=dev)
         got = blk(x)
-        mm.SPLIT3_LINEAR = False
+        mm.set_kernel_config(blk, dataclasses.replace(mm.DEFAULT_CONFIG, linear_three_bf16=False))      # rocBLAS fp32 Linears
         try:
             want = blk(x)
         finally:
-            mm.SPLIT3_LINEAR = True
+            mm.set_kernel_config(blk, mm.DEFAULT_CONFIG)
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
 
 
@@ -214,11 +215,11 @@ def test_convnext_block_fused_matches_module_path():
         blk.mlp.grn.bias.normal_()
         x = torch.randn(3, 128, 24, 24, device=dev)
         got = blk(x)
-        mm.SPLIT3_LINEAR = False
+        mm.set_kernel_config(blk, dataclasses.replace(mm.DEFAULT_CONFIG, linear_three_bf16=False))      # rocBLAS fp32 Linears
         try:
             want = blk(x)
         finally:
-            mm.SPLIT3_LINEAR = True
+            mm.set_kernel_config(blk, mm.DEFAULT_CONFIG)
     assert got.shape == want.shape
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
 

@@ -423,11 +423,11 @@ def test_split2h_path_matches_oracle_and_legacy(model_and_sd):
     with torch.no_grad():
         assert m._h2_ok(x.cuda())
         e2 = m(x.cuda()).cpu()
-        mm.SPLIT2H_DENSENET = False
+        old = m.configure(densenet_two_fp16=False)
         try:
             e3 = m(x.cuda()).cpu()
         finally:
-            mm.SPLIT2H_DENSENET = True
+            m.configure(**old.__dict__)
         ref = OD.embed(x, sd)
     per = lambda a, b: [f"{v:.1e}" for v in (a - b).abs().amax(1).tolist()]      # noqa: E731
     assert float((e2 - ref).abs().max()) <= 1e-5, (per(e2, ref), per(e3, ref), per(e2, e3))
@@ -465,7 +465,7 @@ def test_concurrent_forwards_on_two_streams_equal_the_sequential_result(model_an
 
 @pytest.mark.gpu
 def test_padded_channel_planes_agree(model_and_sd):
-    """Padded channel planes (mirx.model.PLANE_STRIDE_H2: measured, no gain, kept as an option of the kernels' ABI) against the
+    """Padded channel planes (KernelConfig.plane_stride: measured, no gain, kept as an option of the kernels' ABI) against the
     packed default on the same weights: the same bits, gaps never read."""
     import mirx.model as mm
     m, sd = model_and_sd
@@ -473,11 +473,11 @@ def test_padded_channel_planes_agree(model_and_sd):
     x[3] *= 12.0
     with torch.no_grad():
         base = m(x.cuda()).cpu()
+        old = m.configure(plane_stride=((28, 800), (14, 224)))
         try:
-            mm.PLANE_STRIDE_H2.update({28: 800, 14: 224})
             alt = m(x.cuda()).cpu()
         finally:
-            mm.PLANE_STRIDE_H2.clear()
+            m.configure(**old.__dict__)
         ref = OD.embed(x, sd)
     assert torch.equal(alt, base)
     assert float((alt - ref).abs().max()) <= 1e-5
@@ -660,11 +660,11 @@ def test_fused_and_two_launch_small_maps_give_the_same_embeddings(model_and_sd):
     x[4] *= 20.0
     with torch.no_grad():
         two = m(x)
-        m.fused_small_maps = True
+        old = m.configure(fused_small_maps=True)
         try:
             fused = m(x)
         finally:
-            m.fused_small_maps = False
+            m.configure(**old.__dict__)
     assert torch.equal(fused, two)
 
 

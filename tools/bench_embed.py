@@ -29,18 +29,23 @@ def main():
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
     ap.add_argument("--fused-small", action="store_true", help="DenseNet: 14 / 7 maps on the one-launch dense layer (A/B arm)")
     a = ap.parse_args()
+    changes = {}
     if a.no_split3_linear:
-        import mirx.model as mm
-        mm.SPLIT3_LINEAR = False
-    import mirx.model as mm
+        changes["linear_three_bf16"] = False
     if a.no_split2h:
-        mm.SPLIT2H_DENSENET = False
+        changes["densenet_two_fp16"] = False
     if a.no_grn_kernel:
-        mm.GRN_SCALE_KERNEL = False
+        changes["grn_scale_kernel"] = False
     if a.no_split2h_attention:
-        mm.SPLIT2H_ATTENTION = False
-    for kv in filter(None, a.plane_stride.split(",")):
-        mm.PLANE_STRIDE_H2[int(kv.split(":")[0])] = int(kv.split(":")[1])
+        changes["attention_two_fp16"] = False
+    if a.plane_stride:
+        changes["plane_stride"] = tuple((int(kv.split(":")[0]), int(kv.split(":")[1])) for kv in a.plane_stride.split(","))
+    if a.no_hip_stem:
+        changes["hip_stem"] = False
+    if a.no_hip_conv1x1:
+        changes["hip_conv1x1"] = False
+    if a.fused_small:
+        changes["fused_small_maps"] = True
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     if a.model == "convnextv2":
@@ -52,9 +57,7 @@ def main():
         m = MedSigLIP().eval().to(dev)
     else:
         m = DenseNet121().eval().to(dev)
-        m.use_hip_stem = not a.no_hip_stem
-        m.use_hip_conv1x1 = not a.no_hip_conv1x1
-        m.fused_small_maps = a.fused_small
+    m.configure(**changes)
     if a.channels_last:
         m = m.to(memory_format=torch.channels_last)
     x = torch.randn(a.batch, 3, a.size, a.size, device=dev)

@@ -24,9 +24,9 @@ for scales in ((1, 1, 1, 1, 1), (1, 30, 1e-3, 1, 1)):
         ref64 = OD.embed(xs.double(), {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}) \
             if os.environ.get("PROBE_F64") else None
         e2 = m(xs.cuda()).cpu()
-        mm.SPLIT2H_DENSENET = False
+        old = m.configure(densenet_two_fp16=False)
         e3 = m(xs.cuda()).cpu()
-        mm.SPLIT2H_DENSENET = True
+        m.configure(**old.__dict__)
     print("scales", scales)
     print("  h2 vs cpu fp32 per image:", [f"{v:.2e}" for v in (e2 - ref).abs().amax(1).tolist()])
     print("  s3 vs cpu fp32 per image:", [f"{v:.2e}" for v in (e3 - ref).abs().amax(1).tolist()])
