@@ -27,12 +27,7 @@ constexpr int V_PLANE = DH * KT * 2;   // bytes of one term of the V^T tile (4 K
 constexpr int BUF = 2 * K_PLANE + 2 * V_PLANE;   // 16 KiB
 
 __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
-    const f32x2 v = {a, b};
-    const bf16x2 vh = __builtin_convertvector(v, bf16x2);
-    const f32x2 r1 = v - __builtin_convertvector(vh, f32x2);
-    const bf16x2 vl = __builtin_convertvector(r1, bf16x2);
-    h = __builtin_bit_cast(unsigned, vh);
-    l = __builtin_bit_cast(unsigned, vl);
+    split2h_pair(a, b, h, l);
 }
 
 // 8 fp32 values -> two fp16x8 fragments

@@ -48,7 +48,9 @@ constexpr int PLANE_B = CP * KC * 2;
 // stage (8 KiB per 16 channels) is as many bytes as a pixel tile's activations, so one tile per workgroup pulls twice the
 // layer's bytes into the CU; two tiles halve the L2 -> LDS weight stream and the weight-fragment reads per MFMA, at 128
 // accumulator registers per lane (two workgroups per CU instead of three).
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT>
+// TABLED: the images a workgroup's pixels can span fit the 8-row oscale table (hw >= 37 with two pixel tiles) -- decided by the
+// launcher, so that the epilogue holds ONE form of the multiply (a run-time choice made the compiler emit both for every value)
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED>
 __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
@@ -148,12 +150,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     v[0] = fmaxf(fmaf(v[0], rsc[2 * j], rsh[2 * j]), 0.f);
                     v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
                 }
-                v = v * x_scale[u];
-                const f16x2 h = __builtin_convertvector(v, f16x2);
-                const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
-                const f16x2 l = __builtin_convertvector(r1, f16x2);
-                ph[j] = __builtin_bit_cast(unsigned, h);
-                pl[j] = __builtin_bit_cast(unsigned, l);
+                unsigned th, tl;
+                split2h_pair(v[0] * x_scale[u], v[1] * x_scale[u], th, tl);
+                ph[j] = th;
+                pl[j] = tl;
             }
             *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B) = ph;
             *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B + PLANE_B) = pl;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 
     const unsigned img_first = (unsigned)p0 / (unsigned)hw;
     const unsigned p_last = (unsigned)(p0 + CP * NPT - 1 < total ? p0 + CP * NPT - 1 : total - 1);
-    const bool tabled = p_last / (unsigned)hw - img_first < KIMG;       // workgroup-uniform: the images the pixels span fit the table
+    constexpr bool tabled = TABLED;
 
     f32x16 acc[2][NN];
 #pragma unroll
@@ -306,15 +306,14 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * j + e;
                         const int ch = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float t = fmaf(acc[mi][ni][r], tabled ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv, sBias[ch]);
+                        float t = fmaf(acc[mi][ni][r], TABLED ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv, sBias[ch]);
                         t = t < 0.f ? 0.f : t;
                         v[e] = t * y_scale;
                     }
-                    const f16x2 hh = __builtin_convertvector(v, f16x2);
-                    const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
-                    const f16x2 ll = __builtin_convertvector(r1, f16x2);
-                    if (j < 4) { h0[j] = __builtin_bit_cast(unsigned, hh); l0[j] = __builtin_bit_cast(unsigned, ll); }
-                    else { h1[j - 4] = __builtin_bit_cast(unsigned, hh); l1[j - 4] = __builtin_bit_cast(unsigned, ll); }
+                    unsigned hh, ll;
+                    split2h_pair(v[0], v[1], hh, ll);
+                    if (j < 4) { h0[j] = hh; l0[j] = ll; }
+                    else { h1[j - 4] = hh; l1[j - 4] = ll; }
                 }
                 uint16_t *dst = yt + (((bimg * 8 + g) * 2) * (int64_t)hw + off) * 16;
                 *reinterpret_cast<u32x4 *>(dst) = h0;
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = fmaf(acc[mi][ni][r], tabled ? sOsc[ep_k[ni]][ch - co0] : sOsc[0][ch - co0] * x_inv, sBias[ch - co0]);
+                    float v = fmaf(acc[mi][ni][r], TABLED ? sOsc[ep_k[ni]][ch - co0] : sOsc[0][ch - co0] * x_inv, sBias[ch - co0]);
                     if (RELU_OUT) v = v < 0.f ? 0.f : v;          // keeps a NaN (fmaxf would turn it into 0)
                     vmax = range_max(vmax, v);
                     yo[(int64_t)ch * yps] = v;
@@ -372,16 +371,22 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
+    // the oscale table has 8 rows: a workgroup's CP * npt pixels span at most (CP * npt - 1) / hw + 2 images
+    const bool tabled = (CP * npt - 1) / hw + 2 <= 8;
 #define MIRX_H2K(P, R, T, N)                                                                               \
+    {                                                                                                      \
+        if (tabled) MIRX_H2KT(P, R, T, N, true) else MIRX_H2KT(P, R, T, N, false)                          \
+    }
+#define MIRX_H2KT(P, R, T, N, TB)                                                                          \
     {                                                                                                      \
         static bool attr_set = false;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N>),    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + N * 2 * PLANE_B)); \
             if (e != hipSuccess) return e;                                                                 \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
                            n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, xps, yps); \
     }
 #define MIRX_H2C(P, R, T)                                                                                  \
@@ -396,6 +401,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
         if (relu_out) MIRX_H2C(false, true, false) else MIRX_H2C(false, false, false)
     }
 #undef MIRX_H2K
+#undef MIRX_H2KT
 #undef MIRX_H2C
     return hipGetLastError();
 }

@@ -112,12 +112,10 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 v[0] *= sc[j >> 1][2 * (j & 1)];
                 v[1] *= sc[j >> 1][2 * (j & 1) + 1];
             }
-            v = v * x_scale;
-            const bf16x2 h = __builtin_convertvector(v, bf16x2);
-            const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
-            const bf16x2 l = __builtin_convertvector(r1, bf16x2);
-            ph[j] = __builtin_bit_cast(unsigned, h);
-            pl[j] = __builtin_bit_cast(unsigned, l);
+            unsigned th, tl;
+            split2h_pair(v[0] * x_scale, v[1] * x_scale, th, tl);
+            ph[j] = th;
+            pl[j] = tl;
         }
         *reinterpret_cast<u32x4 *>(sb + x_lds) = ph;
         *reinterpret_cast<u32x4 *>(sb + x_lds + PLANE) = pl;

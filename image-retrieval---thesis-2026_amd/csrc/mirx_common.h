@@ -161,6 +161,22 @@ __device__ inline void range_scales(float bound, float &x_scale, float &inv) {
     }
 }
 
+// The two fp16 terms of a pair of fp32 values: hi = RNE(v) (one v_cvt_pk_f16_f32), lo = RNE(v - hi) where v - hi comes from
+// v_fma_mix_f32, which reads the fp16 half in place (exact: the difference of a float and its fp16 rounding is a float).  The
+// compiler's form of `v - float(hi)` converts hi back with an SDWA instruction per value and subtracts with a packed fp32 op:
+// five instructions per pair, two of them the kind that cost 10+ cycles beside an MFMA stream; this is four plain ones.
+__device__ inline void split2h_pair(float v0, float v1, unsigned &hi, unsigned &lo) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    const f32x2_ vv = {v0, v1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, f16x2_));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v1));
+    const f32x2_ rr = {r0, r1};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, f16x2_));
+}
+
 #endif  // __HIPCC__
 
 }  // namespace mirx
