@@ -297,6 +297,50 @@ def host_resident_inputs(model, index, args, dev, steps=4):
             "input": "uint8 [B, 3, H, W] in pinned host memory, normalised inside the stem kernel", "steps": steps}
 
 
+def retriever_single_query(model, args, dev, rows=200_000, calls=40):
+    """The reference's per-query loop (milvus_retrieval.py:53-86, evaluate_test_dataset_milvus.py:446-460): ONE PIL image ->
+    transform -> model(img[None]) -> top-k, through mirx.retriever.MilvusRetriever.search.  queries/s and where the time goes
+    (the B = 1 forward is 125 dependent launches: DESIGN 11)."""
+    import numpy as np
+    from PIL import Image
+    from mirx.retriever import MilvusManager, MilvusRetriever, default_transform
+    mgr = MilvusManager(device=dev)
+    mgr.connect()
+    mgr.create_collection("densenet121", drop_old=True)
+    col = mgr.collections["densenet121"]
+    g = torch.Generator(device=dev).manual_seed(7)
+    for s0 in range(0, rows, 50_000):
+        n = min(50_000, rows - s0)
+        emb = torch.nn.functional.normalize(torch.randn((n, args.dim), generator=g, device=dev), dim=1)
+        col.insert([[f"img_{s0 + i}.png" for i in range(n)], ["normal"] * n, emb])
+    r = MilvusRetriever(mgr, "densenet121", model, default_transform(args.image_size))
+    r.load_collection()
+    img = Image.fromarray(np.random.default_rng(0).integers(0, 256, (300, 280, 3), dtype=np.uint8))
+    for _ in range(3):
+        r.search(img, top_k=args.k)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        r.search(img, top_k=args.k)
+    torch.cuda.synchronize(dev)
+    per = (time.perf_counter() - t0) / calls
+    x = r.transform(img).unsqueeze(0).to(dev)
+    t1 = time.perf_counter()
+    for _ in range(calls):
+        r.transform(img)
+    t_tf = (time.perf_counter() - t1) / calls
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(calls):
+            model(x)
+    torch.cuda.synchronize(dev)
+    t_fw = (time.perf_counter() - t2) / calls
+    return {"queries_per_s": 1.0 / per, "ms_per_query": per * 1e3, "ms_transform_cpu": t_tf * 1e3, "ms_forward_b1": t_fw * 1e3,
+            "gallery_rows": rows, "k": args.k, "note": "MilvusRetriever.search(PIL image): resize + crop + normalise on the host, "
+            "B = 1 forward, exact top-k, result dicts"}
+
+
 def extras(args, dev):
     """Configs 3-5 of BASELINE.json on this GPU (embed stage, native resolution, fp32, synthetic images, random-init
     weights) and the search stage at their embedding widths over a 1M-row gallery."""
@@ -610,6 +654,7 @@ def main():
         if world == 1 and not args.no_extras and not args.search_only:
             ab = overlap_ab(model, index, pool, args, dev) if args.embed_batch % 2 == 0 else None
             hri = host_resident_inputs(model, index, args, dev) if args.embed_batch % 2 == 0 and args.image_size == 224 else None
+            rsq = retriever_single_query(model, args, dev) if args.dim == 1024 else None
             del model, index, searcher, pool
             torch.cuda.empty_cache()
             line["extras"] = extras(args, dev)
@@ -617,6 +662,8 @@ def main():
                 line["extras"]["overlap_search_with_embed"] = ab
             if hri is not None:
                 line["extras"]["host_resident_inputs"] = hri
+            if rsq is not None:
+                line["extras"]["retriever_single_query"] = rsq
             line["roofline"]["other_dims"] = {k: {kk: v[kk] for kk in ("gemm_ms", "gemm_tflops", "gemm_frac_of_bf16_peak")}
                                               for k, v in line["extras"].items() if k.startswith("search_only_")}
         print(json.dumps(line), flush=True)
