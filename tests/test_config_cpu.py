@@ -1,0 +1,60 @@
+"""Host-side pieces added in round 3 that need no GPU: the frozen per-model kernel configuration, the uint8 normalisation the
+stem kernel's table reproduces, and the algorithmic-work formulas bench.py prices the other backbones with."""
+import dataclasses
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernel_config_is_frozen_per_model_and_reaches_every_submodule():
+    import mirx.model as mm
+    a, b = mm.DenseNet121(), mm.DenseNet121()
+    assert a.kernel_config == mm.DEFAULT_CONFIG and not a.kernel_config.fused_small_maps
+    old = a.configure(fused_small_maps=True, plane_stride=((14, 224),))
+    assert old == mm.DEFAULT_CONFIG
+    assert a.kernel_config.fused_small_maps and b.kernel_config == mm.DEFAULT_CONFIG          # another instance is untouched
+    assert all(m._mirx_cfg is a.kernel_config for m in a.modules())
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        a.kernel_config.fused_small_maps = False
+    with pytest.raises(TypeError):
+        a.configure(no_such_switch=True)
+    a.configure(**old.__dict__)
+    assert a.kernel_config == mm.DEFAULT_CONFIG
+    assert not hasattr(mm, "SPLIT2H_DENSENET") and not hasattr(mm, "PLANE_STRIDE_H2")          # no module-level switches left
+    blk = mm._VitBlock(64, 4)
+    assert mm._cfg(blk.attn.qkv) is mm.DEFAULT_CONFIG                                            # a block used on its own: the defaults
+    mm.set_kernel_config(blk, dataclasses.replace(mm.DEFAULT_CONFIG, linear_three_bf16=False))
+    assert not mm._cfg(blk.mlp.fc1).linear_three_bf16
+
+
+def test_uint8_input_is_the_reference_transform_on_the_cpu_path():
+    """forward() on uint8 = forward() on (u / 255 - mean) / std, the fp32 operations of ToTensor + Normalize (test.py:1309-1332)."""
+    import mirx.model as mm
+    torch.manual_seed(0)
+    m = mm.DenseNet121().eval()
+    u8 = torch.randint(0, 256, (2, 3, 64, 64), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    xf = (u8.float() / 255.0 - mean) / std
+    assert torch.equal(m.normalize_uint8(u8), xf)
+    with torch.no_grad():
+        assert torch.equal(m(u8), m(xf))
+    assert "input_mean" not in m.state_dict()                   # non-persistent buffers: reference checkpoints load unchanged
+
+
+def test_algorithmic_work_formulas_have_the_known_answers():
+    """bench.py prices configs 3-5 with these: ConvNeXtV2-base at 384 x 384 is ~45 GMAC; a ViT block is
+    24 T C^2 + 4 T^2 C FLOP."""
+    sys.path.insert(0, ROOT)
+    import bench
+    flop, nbytes = bench.convnextv2_work(384)
+    assert 44.5e9 < flop / 2 < 45.6e9
+    assert 0.6e9 < nbytes < 0.75e9
+    t, c = 1370, 768
+    flop, nbytes = bench.vit_work(t, c, 4 * c, 12, 588)
+    assert abs(flop - (2.0 * t * 588 * c + 12 * (24.0 * t * c * c + 4.0 * t * t * c))) < 1e6
+    assert abs(nbytes - 4.0 * (t * (588 + c) + 12 * 20 * t * c)) < 1e3
