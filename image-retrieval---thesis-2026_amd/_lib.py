@@ -58,6 +58,9 @@ SYMBOLS = {
     "mirx_rank_metrics": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _int, _int, ctypes.c_double, _int,
                                  ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp, _vp, _vp, _vp]),
     "mirx_linear_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "mirx_rows_to_terms": (_int, [_vp, _i64, _int, _i64, ctypes.c_float, _vp, _vp]),
+    "mirx_layernorm_terms": (_int, [_vp, _i64, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "mirx_linear_terms": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp]),
     "mirx_linear_split3": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split2h_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,
@@ -97,7 +100,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 300          # include/mirx.h MIRX_VERSION this binding was written against
+ABI_VERSION = 301          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():

@@ -35,6 +35,12 @@ typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
         __syncthreads();                                     \
     } while (0)
 
+// Diagnostic builds (results wrong; attribute the kernel's time): -DMIRX_LH2_EXP=1 no fp16 split (raw bits staged),
+// 2 no x loads inside the K loop, 3 plain-store epilogue (no activation / residual), 4 no MFMAs
+#ifndef MIRX_LH2_EXP
+#define MIRX_LH2_EXP 0
+#endif
+
 constexpr int TM = 128;            // tokens per workgroup
 constexpr int TN = 128;            // outputs per workgroup
 constexpr int KC = 16;             // features per stage
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
         }
     };
     auto load_x = [&](int kt, f32x4 (&r)[2], f32x4 (&sc)[2]) {
+        if (MIRX_LH2_EXP == 2 && kt > 1) return;
         r[0] = *reinterpret_cast<const f32x4 *>(xsrc + kt * KC);
         r[1] = *reinterpret_cast<const f32x4 *>(xsrc + kt * KC + 4);
         if (GRN) {
@@ -113,7 +120,12 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 v[1] *= sc[j >> 1][2 * (j & 1) + 1];
             }
             unsigned th, tl;
-            split2h_pair(v[0] * x_scale, v[1] * x_scale, th, tl);
+            if (MIRX_LH2_EXP == 1) {
+                th = __float_as_uint(v[0]);
+                tl = __float_as_uint(v[1]);
+            } else {
+                split2h_pair(v[0] * x_scale, v[1] * x_scale, th, tl);
+            }
             ph[j] = th;
             pl[j] = tl;
         }
@@ -155,6 +167,11 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 f32x16 c = acc[mi][ni];
+                if (MIRX_LH2_EXP == 4) {
+                    c[0] += (float)a[mi][0][0] + (float)a[mi][1][1] + (float)b[ni][0][2] + (float)b[ni][1][3];
+                    acc[mi][ni] = c;
+                    continue;
+                }
                 // smallest terms first; NCHW: outputs on the MFMA rows, tokens on the lanes
 #define MIRX_L3_MFMA(TA, TB)                                                                               \
     c = NCHW ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ni][TB], a[mi][TA], c, 0, 0, 0)                    \
@@ -237,9 +254,11 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= m) continue;
                 float v = acc[mi][ni][r] * out_scale + bv;
-                if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                if (MIRX_LH2_EXP != 3) {
+                    if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     if (ACT == 2) v = gelu_tanh(v);
-                if (RES) v = res[row * n + col] + gv * v;
+                    if (RES) v = res[row * n + col] + gv * v;
+                }
                 y[row * n + col] = v;
             }
     }

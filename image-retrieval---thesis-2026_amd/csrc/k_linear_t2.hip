@@ -1,0 +1,448 @@
+// k_linear_t2.hip -- token-major Linear on two fp16 terms per operand (k_linear_h2's arithmetic: three MFMAs per product
+// block, xl wh + xh wl + xh wh, fp32 accumulation), restructured so that the matrix pipe, not the operand delivery, paces it.
+//
+// Why a second kernel: k_linear_h2 takes fp32 activations, splits them in registers while it stages 16 features at a time and
+// synchronises once per 16-feature stage.  A diagnostic build WITHOUT its MFMAs takes 75 % of the full kernel's time (DESIGN
+// 6.4): loads, splits, LDS stores and barriers are the kernel; the MFMAs hide behind them.  Here
+//   * the ACTIVATIONS ARRIVE ALREADY SPLIT ("terms rows", below): the producer (LayerNorm, the previous Linear's epilogue,
+//     attention, or k_rows_to_terms) writes hi | lo fp16 instead of fp32 -- the same 4 bytes per element -- so both operands
+//     go global -> LDS by `buffer_load ... lds` DMA in full 128-byte lines: no staging registers, no VALU, no LDS stores;
+//   * the tile is 256 tokens x 256 outputs per CU (one 8-wave workgroup, wave tile 128 tokens x 64 outputs): an L2-served
+//     LDS fill sustains about 70 GB/s per CU (MI355X_MICROARCH.md, gather into LDS), and a first version of this kernel on
+//     two independent 128 x 128 workgroups per CU needed 71 GB/s to keep the matrix pipe fed -- it measured 39 GB/s, a
+//     stage as long as the fill's latency, 0.50-0.56 matrix-busy.  This tile needs 35 GB/s;
+//   * a stage is 32 features (one 128-byte line per row: 96 MFMAs per wave per barrier instead of 12), two 64-KiB LDS
+//     buffers, v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on this shape than on 32x32x16);
+//   * the barrier sits INSIDE a stage's MFMA stream, after the wave's last LDS read of the stage: the last quarter runs
+//     from registers while the DMA of the stage after next is issued and the next stage's first fragments are read.
+//
+// TERMS ROWS: a [rows][K] matrix scaled by a power of two s, stored as rows of ceil(K / 32) lines of 128 bytes:
+//   line g of a row = fp16 hi(s x[32 g .. 32 g + 31]) | fp16 lo(..)   with hi = fp16(s x), lo = fp16(s x - hi)
+// (features beyond K are zero).  A line is exactly where the fp32 values of those 32 features would have lived.
+//
+// LDS image of a stage (the distance GEMM's, k_gemm.hip): operand tile rows of 128 B; 16-byte chunk c of row r sits at
+// r * 128 + ((c ^ ((r >> 1) & 7)) << 4) -- the XOR is applied to the DMA's SOURCE address, the LDS side of a DMA piece is
+// lane-linear -- chunks 0-3 = hi, 4-7 = lo; a 16x16x32 fragment read (16 rows x 4 chunks of one term) is conflict-free.
+#include "mirx_kernels.h"
+
+namespace mirx {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+constexpr int TM = 256;                  // tokens per workgroup
+constexpr int TN = 256;                  // outputs per workgroup
+constexpr int LINE = 128;                // bytes of one row of one stage: 32 features x (hi | lo)
+constexpr int X_BYTES = TM * LINE;       // 32 KiB
+constexpr int W_BYTES = TN * LINE;       // 32 KiB
+constexpr int STAGE = X_BYTES + W_BYTES; // 64 KiB
+constexpr int LDS_BYTES = 2 * STAGE;
+
+// Diagnostic builds (results wrong), -DMIRX_LT2_EXP=<bit mask>: 1 no MFMAs, 2 no DMA inside the K loop, 4 plain-store
+// epilogue, 8 no workgroup barrier in the K loop, 16 no LDS reads in the K loop, 32 print cycle stamps (K loop cycles per
+// stage, epilogue cycles, the clock the kernel held) from a few workgroups
+#ifndef MIRX_LT2_EXP
+#define MIRX_LT2_EXP 0
+#endif
+
+#if MIRX_LT2_EXP & 32
+__device__ unsigned long long g_lt2_stamps[4096 * 8];      // per workgroup (mod 4096): see the kernel's last lines
+#endif
+
+// ACT: 0 none, 1 GELU (erf), 2 GELU (tanh).  RES: y = res + gamma * v.  TOUT: the result is written as terms rows.
+template <int ACT, bool RES, bool TOUT>
+__global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ xt, int64_t m, int kp,
+                                                      const char *__restrict__ wt, const float *__restrict__ bias, int n,
+                                                      const float *res, const float *__restrict__ gamma, float out_scale,
+                                                      float *y, char *yt, float y_scale, int np, int ntn,
+                                                      int64_t total_tiles, int64_t per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= total_tiles) return;
+    const int tn = (int)(tile % ntn);
+    const int64_t m0 = (tile / ntn) * TM;
+    const int n0 = tn * TN;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wtok = wave >> 2, wout = wave & 3;              // this wave: tokens 128 wtok .., outputs 64 wout ..
+    const int nk = kp >> 5;
+    const int pitch = kp * 4;                                 // bytes of a terms row
+
+    // ---- DMA addressing: piece p = tile rows 8 p .. 8 p + 7 (1 KiB); wave w moves pieces w, w + 8, w + 16, w + 24 of each
+    // operand.  Lane l: row 8 p + (l >> 3), LDS slot l & 7 <- source chunk (l & 7) ^ ((row >> 1) & 7).  Rows beyond the
+    // matrix are outside the descriptor: they read as zero.
+    const int prow = wave * 8 + (lane >> 3);
+    const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+    int vo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vo[i] = (prow + 64 * i) * pitch + pchunk * 16;
+    const int64_t rows_here = m - m0 < TM ? m - m0 : TM;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(xt + m0 * pitch), 0, (int)rows_here * pitch, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(wt + (int64_t)n0 * pitch), 0, TN * pitch, 0x00020000);
+#define DMA_X(BUF, I, KT) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, LDS_PTR(sm + (BUF) * STAGE + ((I) * 8 + wave) * 1024), 16, vo[I], (KT) * LINE, 0, 0)
+#define DMA_W(BUF, I, KT) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, LDS_PTR(sm + (BUF) * STAGE + X_BYTES + ((I) * 8 + wave) * 1024), 16, vo[I], (KT) * LINE, 0, 0)
+
+    // ---- fragment addressing: lane -> row (lane & 15), chunk (lane >> 4) of the term; lo = hi ^ 64 ------------------
+    const int sw = (lane & 15) >> 1;
+    const int fr = (((lane >> 4) ^ sw) << 4);
+    const int xh = (wtok * 128 + (lane & 15)) * LINE + fr, xl = xh ^ 64;
+    const int wh = X_BYTES + (wout * 64 + (lane & 15)) * LINE + fr, wl = wh ^ 64;
+    // buffer 1 sits 64 KiB up -- beyond the 16-bit offset field of ds_read -- so its bases are registers of their own
+    const int xh1 = xh + STAGE, xl1 = xl + STAGE, wh1 = wh + STAGE, wl1 = wl + STAGE;
+#define LDXR(BUF, TI, T) (*reinterpret_cast<const f16x8 *>(sm + ((BUF) ? ((T) ? xl1 : xh1) : ((T) ? xl : xh)) + (TI) * 16 * LINE))
+#define LDWR(BUF, OI, T) (*reinterpret_cast<const f16x8 *>(sm + ((BUF) ? ((T) ? wl1 : wh1) : ((T) ? wl : wh)) + (OI) * 16 * LINE))
+#if MIRX_LT2_EXP & 16
+#define LDX(BUF, TI, T) fx[(TI) & 3][T]
+#define LDW(BUF, OI, T) fw[OI][T]
+#else
+#define LDX(BUF, TI, T) LDXR(BUF, TI, T)
+#define LDW(BUF, OI, T) LDWR(BUF, OI, T)
+#endif
+
+    // accumulator register r of tile (oi, ti): output 64 wout + 16 oi + 4 (lane >> 4) + r, token 128 wtok + 16 ti + (lane & 15)
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int oi = 0; oi < 4; ++oi)
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) acc[oi][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments: the four output tiles of the stage stay in registers (fw), the eight token tiles roll through four slots
+    // (fx[ti & 3]), read up to three token tiles ahead of their MFMAs
+    f16x8 fw[4][2], fx[4][2];
+
+    // the three products of one accumulator tile, smallest terms first
+#if MIRX_LT2_EXP & 1
+#define T3(OI, TI) acc[OI][TI][0] += (float)fw[OI][1][0] + (float)fx[(TI) & 3][1][1] + (float)fw[OI][0][2] + (float)fx[(TI) & 3][0][3];
+#else
+#define T3(OI, TI)                                                                                                   \
+    acc[OI][TI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[OI][1], fx[(TI) & 3][0], acc[OI][TI], 0, 0, 0);          \
+    acc[OI][TI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[OI][0], fx[(TI) & 3][1], acc[OI][TI], 0, 0, 0);          \
+    acc[OI][TI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[OI][0], fx[(TI) & 3][0], acc[OI][TI], 0, 0, 0);
+#endif
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#if MIRX_LT2_EXP & 32
+    unsigned long long st_wait = 0, st_bar = 0, st_p2 = 0, st_p1 = 0, st_t = 0;
+#define STAMP(ACC)                                                   \
+    {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ACC += now_ - st_t;                                          \
+        st_t = now_;                                                 \
+    }
+#else
+#define STAMP(ACC)
+#endif
+#if MIRX_LT2_EXP & 8
+#define KBARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#elif MIRX_LT2_EXP & 32
+#define KBARRIER()                                                   \
+    do {                                                             \
+        STAMP(st_p1)                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        STAMP(st_wait)                                               \
+        __builtin_amdgcn_s_barrier();                                \
+        STAMP(st_bar)                                                \
+    } while (0)
+#else
+#define KBARRIER()                                                   \
+    do {                                                             \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        __builtin_amdgcn_s_barrier();                                \
+    } while (0)
+#endif
+    // A stage (buffer BUF) runs as two parts with the workgroup barrier between them:
+    //   PART1: token tiles 0-4 against the four output tiles (fw and fx of token tile 0 are in registers on entry); token
+    //          tiles 1-3 are read at once, then tile ti + 3 while tile ti multiplies -- with tile 4's read (tile 7) the wave
+    //          has all it needs from BUF
+    //   barrier: every wave has read all it needs of BUF, and the other buffer's DMA (issued one stage ago) has landed
+    //   PART2: token tiles 5-7 from registers, output tile by output tile, so that each fw fragment can be re-read for the
+    //          NEXT stage (other buffer) after its last use; the next stage's token tile 0 is read into the one free slot;
+    //          the DMA of stage KT + 2 goes into BUF
+    // The K loop's body is PART2(stage) PART1(stage + 1), so its back edge falls on the barrier, where every counter is
+    // drained anyway.  `more` (wave-uniform) guards only DMA instructions: no branch encloses an MFMA.
+#if MIRX_LT2_EXP & 2
+#define DMA_ON false
+#else
+#define DMA_ON true
+#endif
+#define P1_READ(BUF, TI)                                                        \
+    fx[(TI) & 3][0] = LDX(BUF, TI, 0);                                          \
+    fx[(TI) & 3][1] = LDX(BUF, TI, 1);
+#define P1_MUL(TI)                                                              \
+    T3(0, TI) T3(1, TI) T3(2, TI) T3(3, TI)                                     \
+    FENCE();
+#define PART1(BUF)                                                              \
+    {                                                                           \
+        P1_READ(BUF, 1) P1_READ(BUF, 2) P1_READ(BUF, 3) P1_MUL(0)               \
+        P1_READ(BUF, 4) P1_MUL(1)                                               \
+        P1_READ(BUF, 5) P1_MUL(2)                                               \
+        P1_READ(BUF, 6) P1_MUL(3)                                               \
+        P1_READ(BUF, 7) P1_MUL(4)                                               \
+    }
+    // A DMA piece stalls the issuing wave for 60-180 cycles (MI355X_MICROARCH.md): the eight pieces a wave owns go into
+    // eight gaps of PART2's MFMA stream, and the two waves that share a SIMD (w and w + 4) use alternate gaps, so that one of
+    // them feeds the matrix pipe while the other stalls.
+#define GAP(G, I, BUF, KT)                                                      \
+    if (more && grp == (G)) {                                                   \
+        DMA_X(BUF, I, (KT) + 2);                                                \
+        DMA_W(BUF, I, (KT) + 2);                                                \
+    }
+#define PART2(BUF, KT)                                                          \
+    {                                                                           \
+        const bool more = DMA_ON && (KT) + 2 < nk;                              \
+        KBARRIER();                                                             \
+        FENCE();                                                                \
+        T3(0, 5)                                                                \
+        fx[0][0] = LDX((BUF) ^ 1, 0, 0);                                        \
+        fx[0][1] = LDX((BUF) ^ 1, 0, 1);                                        \
+        GAP(0, 0, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(0, 6)                                                                \
+        GAP(1, 0, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(0, 7) T3(1, 5)                                                       \
+        GAP(0, 1, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(1, 6)                                                                \
+        fw[0][0] = LDW((BUF) ^ 1, 0, 0);                                        \
+        fw[0][1] = LDW((BUF) ^ 1, 0, 1);                                        \
+        GAP(1, 1, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(1, 7) T3(2, 5)                                                       \
+        GAP(0, 2, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(2, 6)                                                                \
+        fw[1][0] = LDW((BUF) ^ 1, 1, 0);                                        \
+        fw[1][1] = LDW((BUF) ^ 1, 1, 1);                                        \
+        GAP(1, 2, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(2, 7) T3(3, 5)                                                       \
+        GAP(0, 3, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(3, 6)                                                                \
+        fw[2][0] = LDW((BUF) ^ 1, 2, 0);                                        \
+        fw[2][1] = LDW((BUF) ^ 1, 2, 1);                                        \
+        GAP(1, 3, BUF, KT)                                                      \
+        FENCE();                                                                \
+        T3(3, 7)                                                                \
+        FENCE();                                                                \
+        fw[3][0] = LDW((BUF) ^ 1, 3, 0);                                        \
+        fw[3][1] = LDW((BUF) ^ 1, 3, 1);                                        \
+        FENCE();                                                                \
+        STAMP(st_p2)                                                            \
+    }
+
+    // ---- prologue: stages 0 and 1 in flight, the first fragments of stage 0 in registers ----------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        DMA_X(0, i, 0);
+        DMA_W(0, i, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            DMA_X(1, i, 1);
+            DMA_W(1, i, 1);
+        }
+    }
+#pragma unroll
+    for (int oi = 0; oi < 4; ++oi) {
+        fw[oi][0] = LDWR(0, oi, 0);
+        fw[oi][1] = LDWR(0, oi, 1);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {                         // (slots 1-3 are read again by PART1; set here for the diagnostic builds)
+        fx[ti][0] = LDXR(0, ti, 0);
+        fx[ti][1] = LDXR(0, ti, 1);
+    }
+    // waves 4-7 are the younger partners on their SIMDs and lose the issue arbitration against waves 0-3, which then wait for
+    // them at every barrier: a static priority evens the two out (k_gemm.hip)
+    const int grp = wave >> 2;
+    if (grp) __builtin_amdgcn_s_setprio(3);
+
+#if MIRX_LT2_EXP & 32
+    const unsigned long long cy0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    st_t = cy0;
+#endif
+    PART1(0)
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 2 < nk; kt += 2) {
+        PART2(0, kt)
+        PART1(1)
+        PART2(1, kt + 1)
+        PART1(0)
+    }
+    if (kt + 2 == nk) {                                      // two stages left
+        PART2(0, kt)
+        PART1(1)
+        PART2(1, kt + 1)                                     // (its "next stage" reads land in registers nobody uses)
+    } else {
+        PART2(0, kt)
+    }
+#undef PART1
+#undef PART2
+#undef P1_READ
+#undef P1_MUL
+#undef GAP
+#undef DMA_ON
+#undef T3
+#undef LDX
+#undef LDW
+#undef LDXR
+#undef LDWR
+#undef DMA_X
+#undef DMA_W
+
+#if MIRX_LT2_EXP & 32
+    const unsigned long long cy1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- epilogue straight from the accumulators: a lane holds 4 consecutive outputs of one token per tile --------------
+    const int colmax = TOUT ? np : n;
+#pragma unroll
+    for (int oi = 0; oi < 4; ++oi) {
+        const int col = n0 + wout * 64 + 16 * oi + 4 * (lane >> 4);
+        if (col >= colmax) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+        if (bias && col < n) bv = *reinterpret_cast<const f32x4 *>(bias + col);
+        if (RES && gamma) gv = *reinterpret_cast<const f32x4 *>(gamma + col);
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+            const int64_t row = m0 + wtok * 128 + 16 * ti + (lane & 15);
+            if (row >= m) continue;
+            f32x4 v = acc[oi][ti];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e] * out_scale + bv[e];
+                if (!(MIRX_LT2_EXP & 4)) {
+                    if (ACT == 1) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+                    if (ACT == 2) t = gelu_tanh(t);
+                }
+                v[e] = t;
+            }
+            if (RES && !(MIRX_LT2_EXP & 4)) {
+                const f32x4 r = *reinterpret_cast<const f32x4 *>(res + row * n + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = r[e] + gv[e] * v[e];
+            }
+            if (TOUT) {
+                unsigned h0, l0, h1, l1;
+                split2h_pair(v[0] * y_scale, v[1] * y_scale, h0, l0);
+                split2h_pair(v[2] * y_scale, v[3] * y_scale, h1, l1);
+                const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                char *dst = yt + row * ((int64_t)np * 4) + (col >> 5) * LINE + (col & 31) * 2;
+                *reinterpret_cast<u32x2 *>(dst) = hi;
+                *reinterpret_cast<u32x2 *>(dst + 64) = lo;
+            } else {
+                *reinterpret_cast<f32x4 *>(y + row * n + col) = v;
+            }
+        }
+    }
+#if MIRX_LT2_EXP & 32
+    const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && wave == 0) {
+        unsigned long long *o = g_lt2_stamps + (blockIdx.x & 4095) * 8;
+        o[0] = cy1 - cy0;                 // K loop cycles
+        o[1] = cy2 - cy1;                 // epilogue cycles
+        o[2] = rt1 - rt0;                 // K loop in 100 MHz ticks
+        o[3] = nk;
+        o[4] = st_p1;
+        o[5] = st_wait;
+        o[6] = st_bar;
+        o[7] = st_p2;
+    }
+#endif
+}
+
+// fp32 rows [m][k] (row stride ldx floats) -> terms rows [m][kp / 32] lines, scaled by the power of two `scale`.
+// thread -> 4 consecutive features: 8 threads write one 128-byte line.
+__global__ __launch_bounds__(256) void k_rows_to_terms(const float *__restrict__ x, int64_t m, int k, int64_t ldx, float scale,
+                                                       char *__restrict__ xt, int kp) {
+    const int per_row = kp >> 2;
+    const int64_t total = m * per_row;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int64_t row = it / per_row;
+        const int c = (int)(it - row * per_row) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < k) {
+            v = *reinterpret_cast<const f32x4 *>(x + row * ldx + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < k) v[e] = x[row * ldx + c + e];
+        }
+        unsigned h0, l0, h1, l1;
+        split2h_pair(v[0] * scale, v[1] * scale, h0, l0);
+        split2h_pair(v[2] * scale, v[3] * scale, h1, l1);
+        const u32x2 hi = {h0, h1}, lo = {l0, l1};
+        char *dst = xt + row * ((int64_t)kp * 4) + (c >> 5) * LINE + (c & 31) * 2;
+        *reinterpret_cast<u32x2 *>(dst) = hi;
+        *reinterpret_cast<u32x2 *>(dst + 64) = lo;
+    }
+}
+
+}  // namespace
+
+#if MIRX_LT2_EXP & 32
+extern "C" int mirx_debug_lt2_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt2_stamps), sizeof(g_lt2_stamps));
+}
+#endif
+
+hipError_t launch_rows_to_terms(const float *x, int64_t m, int k, int64_t ldx, float scale, void *xt, hipStream_t st) {
+    if (m <= 0) return hipSuccess;
+    if (k < 1 || ldx < k || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return hipErrorInvalidValue;
+    const int kp = (k + 31) / 32 * 32;
+    const int64_t total = m * (kp >> 2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_rows_to_terms, dim3((unsigned)blocks), dim3(256), 0, st, x, m, k, ldx, scale,
+                       reinterpret_cast<char *>(xt), kp);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, const float *bias, int n, int act,
+                            const float *res, const float *gamma, float out_scale, float *y, void *yt, float y_scale,
+                            hipStream_t st) {
+    if (m <= 0) return hipSuccess;
+    if (k < 1 || n < 4 || (n & 3) || act < 0 || act > 2 || (!y && !yt) || (y && yt) || (yt && res) || (gamma && !res))
+        return hipErrorInvalidValue;
+    const int kp = (k + 31) / 32 * 32, np = (n + 31) / 32 * 32;
+    const int ntn = (n + TN - 1) / TN;                 // wt holds ntn * 256 rows, zero beyond n
+    const int64_t total = ((m + TM - 1) / TM) * ntn;
+    const int64_t per_xcd = (total + 7) / 8;
+    if (per_xcd * 8 > 0x7fffffff || (int64_t)TM * kp * 4 > 0x7fffffff) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(per_xcd * 8));
+#define MIRX_T2(A, R, T)                                                                                               \
+    {                                                                                                                  \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_t2<A, R, T>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                 \
+            if (e != hipSuccess) return e;                                                                             \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_linear_t2<A, R, T>), grid, dim3(512), LDS_BYTES, st, reinterpret_cast<const char *>(xt), m, kp, \
+                           reinterpret_cast<const char *>(wt), bias, n, res, gamma, out_scale, y,                      \
+                           reinterpret_cast<char *>(yt), y_scale, np, ntn, total, per_xcd);                            \
+    }
+    if (yt) {
+        if (act == 2) MIRX_T2(2, false, true) else if (act == 1) MIRX_T2(1, false, true) else MIRX_T2(0, false, true)
+    } else if (res) {
+        if (act) return hipErrorInvalidValue;
+        MIRX_T2(0, true, false)
+    } else {
+        if (act == 2) MIRX_T2(2, false, false) else if (act == 1) MIRX_T2(1, false, false) else MIRX_T2(0, false, false)
+    }
+#undef MIRX_T2
+    return hipGetLastError();
+}
+
+}  // namespace mirx

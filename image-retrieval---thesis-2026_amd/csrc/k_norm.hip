@@ -22,6 +22,7 @@ namespace mirx {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -31,9 +32,13 @@ __device__ inline float wave_sum(float v) {
 
 // ---- LayerNorm over rows ----------------------------------------------------------------------------------------
 // grid: ceil(m / 4) workgroups of 4 waves; wave w normalises row 4 * blockIdx.x + w.  c % 4 == 0.
+// TERMS: the result is written as "terms rows" (k_linear_t2.hip: line g of a row = fp16 hi | lo of scale * y[32 g .. 32 g + 31],
+// the input format of the DMA-fed Linear) instead of fp32 -- the same bytes, and the Linear that follows needs no split.
+template <bool TERMS>
 __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict__ x, int64_t m, int c,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                        float eps, float *__restrict__ y) {
+                                                        float eps, float *__restrict__ y, char *__restrict__ yt, float scale,
+                                                        int cp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -53,15 +58,28 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict_
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
     f32x4 *yr = reinterpret_cast<f32x4 *>(y + row * c);
-    for (int i = lane; i < nv; i += 64) {
-        const f32x4 v = xr[i];
-        f32x4 o;
+    char *tr = yt + row * ((int64_t)cp * 4);
+    for (int i = lane; i < (TERMS ? cp >> 2 : nv); i += 64) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (!TERMS || i < nv) {
+            const f32x4 v = xr[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float g = gamma ? gamma[4 * i + j] : 1.f, b = beta ? beta[4 * i + j] : 0.f;
-            o[j] = (v[j] - mean) * rstd * g + b;
+            for (int j = 0; j < 4; ++j) {
+                const float g = gamma ? gamma[4 * i + j] : 1.f, b = beta ? beta[4 * i + j] : 0.f;
+                o[j] = (v[j] - mean) * rstd * g + b;
+            }
         }
-        yr[i] = o;
+        if (TERMS) {
+            unsigned h0, l0, h1, l1;
+            split2h_pair(o[0] * scale, o[1] * scale, h0, l0);
+            split2h_pair(o[2] * scale, o[3] * scale, h1, l1);
+            const u32x2 hi = {h0, h1}, lo = {l0, l1};
+            char *dst = tr + (i >> 3) * 128 + (i & 7) * 8;
+            *reinterpret_cast<u32x2 *>(dst) = hi;
+            *reinterpret_cast<u32x2 *>(dst + 64) = lo;
+        } else {
+            yr[i] = o;
+        }
     }
 }
 
@@ -218,9 +236,17 @@ __global__ __launch_bounds__(256) void k_attention_small(const float *__restrict
 }  // namespace
 
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
-                                 float *y, int tokens_per_image, hipStream_t st) {
+                                 float *y, int tokens_per_image, hipStream_t st, void *yt, float scale) {
     if (m <= 0) return hipSuccess;
     if (c < 4 || c % 4) return hipErrorInvalidValue;
+    if (yt) {
+        if (tokens_per_image > 0 || y) return hipErrorInvalidValue;
+        const int64_t blocks = (m + 3) / 4;
+        if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_layernorm_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, nullptr,
+                           reinterpret_cast<char *>(yt), scale, (c + 31) / 32 * 32);
+        return hipGetLastError();
+    }
     if (tokens_per_image > 0) {
         if (c > 512) return hipErrorInvalidValue;
         const size_t lds = (size_t)c * 65 * sizeof(float);
@@ -232,7 +258,8 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
     } else {
         const int64_t blocks = (m + 3) / 4;
         if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_layernorm_rows, dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, y);
+        hipLaunchKernelGGL(k_layernorm_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, y, nullptr,
+                           1.f, 0);
     }
     return hipGetLastError();
 }

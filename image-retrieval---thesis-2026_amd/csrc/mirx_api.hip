@@ -888,6 +888,41 @@ int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null,
     return MIRX_OK;
 }
 
+int mirx_layernorm_terms(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
+                         float scale, void *yt, void *stream) {
+    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0, "layernorm_terms: c must be a multiple of 4");
+    MIRX_CHECK(m == 0 || (x && yt), "layernorm_terms: null buffer");
+    MIRX_CHECK(eps >= 0.f && scale > 0.f, "layernorm_terms: eps must be non-negative and scale positive");
+    MIRX_HIP(launch_layernorm_rows(x, m, c, gamma_or_null, beta_or_null, eps, nullptr, 0, reinterpret_cast<hipStream_t>(stream),
+                                   yt, scale));
+    return MIRX_OK;
+}
+
+int mirx_rows_to_terms(const float *x, int64_t m, int k, int64_t row_stride, float scale, void *xt, void *stream) {
+    MIRX_CHECK(m >= 0 && k >= 1 && row_stride >= k && row_stride % 4 == 0, "rows_to_terms: bad geometry (row_stride % 4 == 0)");
+    MIRX_CHECK(m == 0 || (x && xt), "rows_to_terms: null buffer");
+    MIRX_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0, "rows_to_terms: x must be 16-byte aligned");
+    MIRX_CHECK(scale > 0.f, "rows_to_terms: scale must be positive");
+    MIRX_HIP(launch_rows_to_terms(x, m, k, row_stride, scale, xt, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const float *bias_or_null, int n, int act,
+                      const float *residual_or_null, const float *gamma_or_null, float out_scale, float *y_or_null,
+                      void *yt_or_null, float yt_scale, void *stream) {
+    MIRX_CHECK(m >= 0 && k >= 1 && n >= 4 && n % 4 == 0, "linear_terms: n must be a multiple of 4");
+    MIRX_CHECK(act >= 0 && act <= 2, "linear_terms: act is 0 (none), 1 (GELU) or 2 (tanh GELU)");
+    MIRX_CHECK(m == 0 || (xt && wt), "linear_terms: null operand");
+    MIRX_CHECK((y_or_null != nullptr) != (yt_or_null != nullptr), "linear_terms: exactly one of y and yt");
+    MIRX_CHECK(!(yt_or_null && residual_or_null), "linear_terms: the terms output has no residual form");
+    MIRX_CHECK(!(residual_or_null && act), "linear_terms: the residual form has no activation");
+    MIRX_CHECK(!gamma_or_null || residual_or_null, "linear_terms: gamma scales the residual form only");
+    MIRX_CHECK(!yt_or_null || yt_scale > 0.f, "linear_terms: yt_scale must be positive");
+    MIRX_HIP(launch_linear_t2(xt, m, k, wt, bias_or_null, n, act, residual_or_null, gamma_or_null, out_scale, y_or_null,
+                              yt_or_null, yt_scale, reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
 int mirx_patchify_nchw(const float *x, int64_t n, int c, int h, int w, int patch, const float *ln_gamma_or_null,
                        const float *ln_beta_or_null, float eps, float *out, int row_stride, void *stream) {
     MIRX_CHECK(n >= 0 && n <= 65535 && c >= 1 && patch >= 1 && h >= patch && w >= patch, "patchify: bad geometry");

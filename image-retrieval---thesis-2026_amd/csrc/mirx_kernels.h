@@ -119,7 +119,12 @@ hipError_t launch_dense_fused(float *buf, int64_t bs, int cin, const float *scal
 
 // ---- k_norm.hip: LayerNorm over rows, patchify (+ LayerNorm2d), attention for short query sets ------------------
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
-                                 float *y, int tokens_per_image, hipStream_t st);
+                                 float *y, int tokens_per_image, hipStream_t st, void *yt = nullptr, float scale = 1.f);
+// k_linear_t2.hip: the DMA-fed two-fp16-term Linear on "terms rows" and the fp32 -> terms conversion
+hipError_t launch_rows_to_terms(const float *x, int64_t m, int k, int64_t ldx, float scale, void *xt, hipStream_t st);
+hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, const float *bias, int n, int act,
+                            const float *res, const float *gamma, float out_scale, float *y, void *yt, float y_scale,
+                            hipStream_t st);
 hipError_t launch_patchify(const float *x, int64_t n, int c, int h, int w, int p, const float *gamma, const float *beta,
                            float eps, float *out, int kpad, hipStream_t st);
 hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, const float *v, int64_t kv_rs,

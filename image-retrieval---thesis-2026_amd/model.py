@@ -100,6 +100,8 @@ class KernelConfig:
     conv3x3_legacy: tuple = ((56, "wino"), (28, "wino3"), (14, "direct3"), (7, "wino"))
     linear_three_bf16: bool = True          # token-major Linears on the MFMA kernels at all (False: rocBLAS fp32)
     linear_two_fp16: bool = True            #   .. on two fp16 terms where the input has a provable bound (LayerNorm outputs)
+    linear_terms_min_rows: int = 4096       #   .. ViT / SigLIP blocks with at least this many token rows: the DMA-fed Linear on pre-split
+                                            #      "terms rows" (k_linear_t2: 256 x 256 tiles); 0 = never
     attention_three_bf16: bool = True       # flash attention on three bf16 terms (False: fp32 MFMAs)
     attention_two_fp16: bool = True         #   .. on two fp16 terms where q / k / v have provable bounds
     grn_scale_kernel: bool = True           # ConvNeXtV2: GRN scale vector + its maximum in one launch (False: five ATen launches)
@@ -557,6 +559,103 @@ def _linear_h2_weights(mod):
         cached = (key, t.permute(1, 3, 0, 2, 4).contiguous(), ws)
         mod._mirx_w2 = cached
     return cached[1], cached[2]
+
+
+def _terms_of(a, scale):
+    """Host-side "terms rows" of `a` [rows, k] * scale (include/mirx.h, mirx_linear_terms): fp16 [rows, ceil32(k) // 32, 2, 32]
+    = per 32-feature group the high terms, then the low terms.  Used for weights (once per layer); activations are converted
+    on the device (mirx_rows_to_terms, mirx_layernorm_terms, the terms output of mirx_linear_terms)."""
+    a = a.float() * scale
+    rows, k = a.shape
+    if k % 32:
+        a = F.pad(a, (0, 32 - k % 32))
+    hi = a.to(torch.float16)
+    lo = (a - hi.float()).to(torch.float16)
+    return torch.stack([hi.view(rows, -1, 32), lo.view(rows, -1, 32)], 2).contiguous()
+
+
+def _linear_terms_weights(mod):
+    """(wt, w_scale): terms rows of W * w_scale, rows padded to a multiple of 256 with zeros; w_scale the power of two that
+    puts the largest |w| in [2^13, 2^14) (the low term stays a normal fp16 number)."""
+    w = mod.weight
+    key = _tkey(w)
+    cached = getattr(mod, "_mirx_wt", None)
+    if cached is None or cached[0] != key:
+        wf = w.detach().float()
+        amax = float(wf.abs().max())
+        ws = 2.0 ** math.floor(math.log2(16384.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        if wf.shape[0] % 256:
+            wf = F.pad(wf, (0, 0, 0, 256 - wf.shape[0] % 256))
+        cached = (key, _terms_of(wf, ws), ws)
+        mod._mirx_wt = cached
+    return cached[1], cached[2]
+
+
+def _terms_scale(bound):
+    """The power of two that brings |x| <= bound to at most 2^15 (fp16 terms overflow at 65504)."""
+    return 2.0 ** math.floor(math.log2(32768.0 / bound))
+
+
+def _rows_to_terms(x, bound):
+    """[HIP] terms rows of x [..., k] (fp32, last axis contiguous) scaled for |x| <= bound -> (xt fp16 [m, ceil32(k) * 2], scale)."""
+    k = x.shape[-1]
+    x = x.reshape(-1, k)
+    if x.stride(-1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    m = x.shape[0]
+    xs = _terms_scale(bound)
+    xt = torch.empty(m, (k + 31) // 32 * 64, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mirx_rows_to_terms(_ptr(x), m, k, x.stride(0), xs, _ptr(xt), _stream(x.device)), "mirx_rows_to_terms")
+    return xt, xs
+
+
+def _layernorm_terms(ln, x, bound):
+    """[HIP] LayerNorm over the last axis written as terms rows (the next Linear's input) -> (xt, scale)."""
+    c = x.shape[-1]
+    x = x.contiguous()
+    m = x.numel() // c
+    xs = _terms_scale(bound)
+    xt = torch.empty(m, (c + 31) // 32 * 64, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mirx_layernorm_terms(_ptr(x), m, c, _ptr(ln.weight.detach()) if ln.weight is not None else None,
+                                                    _ptr(ln.bias.detach()) if ln.bias is not None else None, float(ln.eps), xs,
+                                                    _ptr(xt), _stream(x.device)), "mirx_layernorm_terms")
+    return xt, xs
+
+
+def _linear_terms(mod, xt, xs, lead, act=0, res=None, gamma=None, out=None, terms_bound=None):
+    """[HIP] y = epi(x W^T + b) through mirx_linear_terms; xt / xs = the input as terms rows and its scale, `lead` the
+    leading shape of the result.  terms_bound: the result is returned as (terms rows, scale) for |y| <= terms_bound instead
+    of fp32 (the fc1 -> fc2 hand-over)."""
+    wt, ws = _linear_terms_weights(mod)
+    m = xt.shape[0]
+    n = mod.out_features
+    dev = xt.device
+    yt = ys = None
+    if terms_bound is not None:
+        ys = _terms_scale(terms_bound)
+        yt = torch.empty(m, (n + 31) // 32 * 64, dtype=torch.float16, device=dev)
+    elif out is None:
+        out = torch.empty(tuple(lead) + (n,), dtype=torch.float32, device=dev)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == out.shape
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mirx_linear_terms(_ptr(xt), m, mod.in_features, _ptr(wt),
+                                                 _ptr(mod.bias.detach()) if mod.bias is not None else None, n, act,
+                                                 _ptr(res) if res is not None else None,
+                                                 _ptr(gamma.detach()) if gamma is not None else None, 1.0 / (xs * ws),
+                                                 _ptr(out) if yt is None else None, _ptr(yt) if yt is not None else None,
+                                                 ys if ys is not None else 1.0, _stream(dev)), "mirx_linear_terms")
+    return (yt, ys) if yt is not None else out
+
+
+def _linear_terms_ok(mod, rows, lins, bounds):
+    """The DMA-fed Linear (mirx_linear_terms) serves a block when the batch fills its 256 x 256 tiles and every input has a
+    provable bound (the same contract as _linear_h2_ok)."""
+    cfg = _cfg(mod)
+    return (cfg.linear_two_fp16 and cfg.linear_three_bf16 and cfg.linear_terms_min_rows > 0 and rows >= cfg.linear_terms_min_rows
+            and all(l.out_features % 4 == 0 for l in lins) and all(math.isfinite(b) and 0.0 < b < 3.0e4 for b in bounds))
 
 
 def _tkey(t):
@@ -1314,8 +1413,16 @@ class _VitBlock(nn.Module):
             x = x.contiguous()
             # the two Linears fed by a LayerNorm have a provable input bound: two fp16 terms (3 MFMAs per product)
             b1, b2 = _layernorm_bound(self.norm1), _layernorm_bound(self.norm2)
-            h1 = _layernorm(self.norm1, x)
-            qkv = _linear_h2(at.qkv, h1, b1) if _linear_h2_ok(at.qkv, h1, b1) else _linear_s3(at.qkv, h1)
+            # attention output = softmax-weighted average of V rows: bounded like the V part of the qkv projection; |gelu(v)| <= |v|
+            ba, bh = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c)), _linear_out_bound(self.norm2, self.mlp.fc1)
+            # big batches: every Linear on the DMA-fed kernel, its input handed over as terms rows by the producer
+            terms = _linear_terms_ok(self, b * n, (at.qkv, at.proj, self.mlp.fc1, self.mlp.fc2), (b1, b2, ba, bh))
+            if terms:
+                h1t, s1 = _layernorm_terms(self.norm1, x, b1)
+                qkv = _linear_terms(at.qkv, h1t, s1, (b, n))
+            else:
+                h1 = _layernorm(self.norm1, x)
+                qkv = _linear_h2(at.qkv, h1, b1) if _linear_h2_ok(at.qkv, h1, b1) else _linear_s3(at.qkv, h1)
             a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 lib = _lib.load()
@@ -1329,8 +1436,12 @@ class _VitBlock(nn.Module):
                     att = lib.mirx_attention_qkv_f32_split3 if _cfg(self).attention_three_bf16 else lib.mirx_attention_qkv_f32
                     _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
                                "mirx_attention_qkv_f32")
-            # attention output = softmax-weighted average of V rows: bounded like the V part of the qkv projection
-            ba = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
+            if terms:
+                att, sa = _rows_to_terms(a, ba)
+                x = _linear_terms(at.proj, att, sa, (b, n), res=x, gamma=self.ls1.gamma)
+                h2t, s2 = _layernorm_terms(self.norm2, x, b2)
+                hidt, sh = _linear_terms(self.mlp.fc1, h2t, s2, (b, n), act=1, terms_bound=bh)
+                return _linear_terms(self.mlp.fc2, hidt, sh, (b, n), res=x, gamma=self.ls2.gamma, out=x)
             x = (_linear_h2(at.proj, a, ba, res=x, gamma=self.ls1.gamma) if _linear_h2_ok(at.proj, a, ba)
                  else _linear_s3(at.proj, a, res=x, gamma=self.ls1.gamma))
             h2 = _layernorm(self.norm2, x)

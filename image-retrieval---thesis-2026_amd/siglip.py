@@ -127,9 +127,16 @@ class _EncoderLayer(nn.Module):
         x = x.contiguous()
         lib = _lib.load()
         b1, b2 = _m._layernorm_bound(self.layer_norm1), _m._layernorm_bound(self.layer_norm2)
-        h1 = _m._layernorm(self.layer_norm1, x)
         pk = sa._packed.refresh()
-        qkv = _m._linear_h2(pk, h1, b1) if _m._linear_h2_ok(pk, h1, b1) else _m._linear_s3(pk, h1)      # [b, n, 3c]
+        bctx, bh = _m._linear_out_bound(self.layer_norm1, sa.v_proj), _m._linear_out_bound(self.layer_norm2, mlp.fc1)
+        # big batches: every Linear on the DMA-fed kernel, its input handed over as terms rows by the producer
+        terms = _m._linear_terms_ok(self, b * n, (pk, sa.out_proj, mlp.fc1, mlp.fc2), (b1, b2, bctx, bh))
+        if terms:
+            h1t, s1 = _m._layernorm_terms(self.layer_norm1, x, b1)
+            qkv = _m._linear_terms(pk, h1t, s1, (b, n))                                                   # [b, n, 3c]
+        else:
+            h1 = _m._layernorm(self.layer_norm1, x)
+            qkv = _m._linear_h2(pk, h1, b1) if _m._linear_h2_ok(pk, h1, b1) else _m._linear_s3(pk, h1)      # [b, n, 3c]
         ctx = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             st = _m._stream(x.device)
@@ -150,7 +157,13 @@ class _EncoderLayer(nn.Module):
                                                     ctypes.c_void_p(base + 8 * c), 3 * c,
                                                     _m._ptr(km) if km is not None else None, b, sa.num_heads, sa.head_dim,
                                                     n, n, float(sa.scale), _m._ptr(ctx), st), "mirx_attention_small")
-        # the context is a softmax-weighted average of V rows: bounded like the V rows of the packed projection
+        # the context is a softmax-weighted average of V rows: bounded like the V rows of the packed projection; |gelu(v)| <= |v|
+        if terms:
+            ct, sc = _m._rows_to_terms(ctx, bctx)
+            x = _m._linear_terms(sa.out_proj, ct, sc, (b, n), res=x)
+            h2t, s2 = _m._layernorm_terms(self.layer_norm2, x, b2)
+            hidt, sh = _m._linear_terms(mlp.fc1, h2t, s2, (b, n), act=2, terms_bound=bh)
+            return _m._linear_terms(mlp.fc2, hidt, sh, (b, n), res=x, out=x)
         x = (_m._linear_h2(sa.out_proj, ctx, bv, res=x) if _m._linear_h2_ok(sa.out_proj, ctx, bv)
              else _m._linear_s3(sa.out_proj, ctx, res=x))
         h2 = _m._layernorm(self.layer_norm2, x)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 300
+#define MIRX_VERSION 301
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -331,6 +331,32 @@ int mirx_linear_split3(const float *x, int64_t m, int k, const void *w3, const f
 int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const float *bias_or_null, int n, int act,
                         const float *residual_or_null, const float *gamma_or_null, float x_scale, float out_scale,
                         float *y, void *stream);
+
+/*
+ * The token-major Linear with BOTH operands pre-split ("terms rows"), the form the ViT / SigLIP towers run on: the same
+ * arithmetic as mirx_linear_split2h (two fp16 terms per operand, three MFMAs per product block, fp32 accumulation), but the
+ * activations arrive already split, so the kernel is a DMA-fed MFMA GEMM (k_linear_t2.hip).  Replaces nn.Linear inside timm
+ * VisionTransformer blocks and transformers SiglipEncoderLayer (model.py:459-463, 553-557 of the reference build them).
+ *
+ * TERMS ROWS of a matrix a [rows][k] scaled by a power of two s: rows of ceil(k / 32) lines of 128 bytes,
+ *     line g = fp16 hi(s a[32 g .. 32 g + 31]) | fp16 lo(..),   hi = fp16(s a), lo = fp16(s a - hi), zero beyond k
+ * -- 4 bytes per element like fp32.  Contract: |s a| <= 65504 for every element (callers pass provable bounds).
+ *
+ * mirx_rows_to_terms:   xt = terms rows of `scale` * x, x = device fp32 [m][k] with `row_stride` floats between rows
+ *                       (row_stride % 4 == 0, x 16-byte aligned).  xt: m * ceil32(k) * 4 bytes.
+ * mirx_layernorm_terms: mirx_layernorm (token-major form) writing terms rows of `scale` * y instead of fp32.
+ * mirx_linear_terms:    v = act( out_scale * sum_k xt[i, k] wt[j, k] + bias[j] ),   out_scale = 1 / (x scale * w scale)
+ *                       act 0 none, 1 GELU (erf), 2 GELU (tanh);
+ *                       y (fp32 [m][n]) = v, or residual + gamma[j] * v (act 0; gamma NULL = 1; y may alias residual);
+ *                       or yt = terms rows of yt_scale * v (no residual) -- the next Linear's input, written in full lines.
+ *                       wt = terms rows of W * w scale, ceil(n / 256) * 256 rows (zero beyond n).  n % 4 == 0.
+ */
+int mirx_rows_to_terms(const float *x, int64_t m, int k, int64_t row_stride, float scale, void *xt, void *stream);
+int mirx_layernorm_terms(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
+                         float scale, void *yt, void *stream);
+int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const float *bias_or_null, int n, int act,
+                      const float *residual_or_null, const float *gamma_or_null, float out_scale, float *y_or_null,
+                      void *yt_or_null, float yt_scale, void *stream);
 
 /*
  * Tail of a ConvNeXtV2 block (timm ConvNeXtBlock.forward, used by the reference's model.py:87-118): the second

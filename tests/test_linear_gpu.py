@@ -293,3 +293,135 @@ def test_linear_tanh_gelu_epilogue(kind):
         got = mm._linear_s3(lin, x, act=2) if kind == "split3" else mm._linear_h2(lin, x, 4.0, act=2)
         want = torch.nn.functional.gelu(lin.double()(x.double()), approximate="tanh")
     assert float((got.double() - want).abs().max()) < 3e-6 * max(1.0, float(want.abs().max()))
+
+
+def _from_terms(t, k, scale):
+    """terms rows (fp16 [m, ceil32(k) * 2]) back to float64 [m, k]"""
+    m = t.shape[0]
+    t = t.view(m, -1, 2, 32).double()
+    return (t[:, :, 0] + t[:, :, 1]).reshape(m, -1)[:, :k] / scale
+
+
+@pytest.mark.parametrize("m,k", [(1, 4), (37, 96), (300, 200), (513, 768), (64, 4304)])
+def test_rows_to_terms_and_layernorm_terms(m, k):
+    """mirx_rows_to_terms / mirx_layernorm_terms: hi + lo reproduces scale * x to 2^-21 of the bound (two fp16 terms), the
+    padding features are zero, and the LayerNorm variant carries exactly the rows mirx_layernorm writes."""
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(m + k)
+    x = (torch.randn(m, k, generator=g) * 3.0).clamp(-20, 20).to(dev)
+    xt, xs = mm._rows_to_terms(x, 20.0)
+    torch.cuda.synchronize()
+    kp = (k + 31) // 32 * 32
+    assert xt.shape == (m, 2 * kp) and xs == 1024.0
+    back = _from_terms(xt, kp, xs)
+    assert float((back[:, :k] - x.double()).abs().max()) <= 20.0 * 2.0 ** -21
+    assert float(back[:, k:].abs().max()) == 0.0 if kp > k else True
+    # a strided view (every second row of a wider matrix) is read in place
+    wide = (torch.randn(2 * m, k + 8, generator=g)).to(dev)
+    if (k + 8) % 4 == 0:
+        vt, vs = mm._rows_to_terms(wide[::2, :k], 8.0)
+        assert float((_from_terms(vt, k, vs) - wide[::2, :k].double()).abs().max()) <= 8.0 * 2.0 ** -21
+    if k % 4 == 0:
+        ln = torch.nn.LayerNorm(k).to(dev)
+        with torch.no_grad():
+            ln.weight.normal_()
+            ln.bias.normal_()
+            bound = mm._layernorm_bound(ln)
+            yt, ys = mm._layernorm_terms(ln, x, bound)
+            want = mm._layernorm(ln, x)
+        torch.cuda.synchronize()
+        assert float((_from_terms(yt, k, ys) - want.double()).abs().max()) <= bound * 2.0 ** -21
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 32, 4), (300, 96, 200), (255, 200, 96), (257, 768, 2304), (1370 * 2 + 5, 768, 768),
+                                   (513, 3072, 768), (260, 1152, 4304), (300, 4304, 1152), (4100, 64, 516)])
+@pytest.mark.parametrize("act,use_res,use_gamma,terms_out", [(0, False, False, False), (1, False, False, False),
+                                                             (2, False, False, True), (0, True, True, False),
+                                                             (0, True, False, False), (1, False, False, True)])
+def test_linear_terms_matches_float64(m, k, n, act, use_res, use_gamma, terms_out):
+    """mirx_linear_terms (csrc/k_linear_t2.hip: both operands pre-split, DMA-fed 256 x 256 tiles) against a float64
+    restatement -- ragged token / output / feature counts, every epilogue, the terms-rows output -- and against
+    mirx_linear_split2h, whose arithmetic it shares (same tolerance class: 3e-6 of the largest |y|)."""
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(m * 3 + k + n + act)
+    xmax = 6.0
+    x = (torch.randn(m, k, generator=g) * 1.5).clamp(-xmax, xmax).to(dev)
+    lin = torch.nn.Linear(k, n).to(dev)
+    with torch.no_grad():
+        lin.bias.normal_()
+    res = torch.randn(m, n, generator=g).to(dev) if use_res else None
+    gamma = torch.randn(n, generator=g).to(dev) if use_gamma else None
+    want = x.double() @ lin.weight.double().t() + lin.bias.double()
+    if act == 1:
+        want = 0.5 * want * (1.0 + torch.erf(want / math.sqrt(2.0)))
+    elif act == 2:
+        want = torch.nn.functional.gelu(want, approximate="tanh")
+    if use_res:
+        want = res.double() + (gamma.double() if use_gamma else 1.0) * want
+    want = want.detach()
+    with torch.no_grad():
+        xt, xs = mm._rows_to_terms(x, xmax)
+        if terms_out:
+            bound = float(want.abs().max()) * 1.01 + 1e-3
+            yt, ys = mm._linear_terms(lin, xt, xs, (m,), act=act, terms_bound=bound)
+            torch.cuda.synchronize()
+            npad = (n + 31) // 32 * 32
+            got = _from_terms(yt, npad, ys)
+            assert float(got[:, n:].abs().max()) == 0.0 if npad > n else True      # the next Linear's padding features
+            got = got[:, :n]
+            tol = 3e-6 * max(1.0, float(want.abs().max())) + bound * 2.0 ** -21
+        else:
+            y = res.clone() if use_res else None
+            got = mm._linear_terms(lin, xt, xs, (m,), act=act, res=y, gamma=gamma, out=y).double()     # in place over the residual
+            torch.cuda.synchronize()
+            tol = 3e-6 * max(1.0, float(want.abs().max()))
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < tol, (err, tol)
+
+
+def test_linear_terms_argument_checks():
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    xt = torch.zeros(4, 64, dtype=torch.float16, device=dev)
+    wt = torch.zeros(256, 64, dtype=torch.float16, device=dev)
+    y = torch.zeros(4, 8, device=dev)
+    f = ctypes.c_float
+    ok = lambda *a: lib.mirx_linear_terms(*a) == 0       # noqa: E731
+    assert ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 6, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)          # n % 4
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 3, None, None, f(1.0), _vp(y), None, f(1.0), None)          # act
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), None, None, f(1.0), None)            # no output
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), _vp(xt), f(1.0), None)       # two outputs
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 1, _vp(y), None, f(1.0), _vp(y), None, f(1.0), None)        # residual + activation
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, _vp(y), f(1.0), _vp(y), None, f(1.0), None)        # gamma without residual
+    assert ok(_vp(xt), 0, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)              # empty batch
+    assert lib.mirx_rows_to_terms(_vp(y), 4, 8, 6, f(1.0), _vp(xt), None) != 0                                   # row_stride < k
+
+
+def test_vit_block_terms_path_matches_split2h_path():
+    """A ViT block on the DMA-fed Linear (LayerNorm -> terms rows, fc1 -> terms rows -> fc2) against the same block on
+    mirx_linear_split2h: the same two-fp16-term arithmetic in another summation order."""
+    import mirx.model as mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    blk = mm._VitBlock(768, 12).to(dev).eval()
+    with torch.no_grad():
+        blk.ls1.gamma.normal_()
+        blk.ls2.gamma.normal_()
+        for p in (blk.attn.qkv.bias, blk.attn.proj.bias, blk.mlp.fc1.bias, blk.mlp.fc2.bias):
+            p.normal_(std=0.1)
+        x = torch.randn(4, 1370, 768, device=dev)
+        x0 = x.clone()
+        assert mm._linear_terms_ok(blk, 4 * 1370, (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2), (1.0,))
+        got = blk(x)
+        assert torch.equal(x, x0)                                                    # the block does not write into its input
+        mm.set_kernel_config(blk, dataclasses.replace(mm.DEFAULT_CONFIG, linear_terms_min_rows=0))
+        try:
+            want = blk(x)
+        finally:
+            mm.set_kernel_config(blk, mm.DEFAULT_CONFIG)
+    assert float((got - want).abs().max()) < 3e-6 * float(want.abs().max())

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--no-grn-kernel", action="store_true", help="ConvNeXtV2: GRN scale vector through ATen")
     ap.add_argument("--no-split2h-attention", action="store_true", help="ViT / SigLIP: three-bf16-term flash attention")
     ap.add_argument("--plane-stride", default="", help="DenseNet: padded channel planes, e.g. 28:800,14:224")
+    ap.add_argument("--no-linear-terms", action="store_true", help="ViT / SigLIP: Linears on mirx_linear_split2h (A/B arm)")
     ap.add_argument("--fused-small", action="store_true", help="DenseNet: 14 / 7 maps on the one-launch dense layer (A/B arm)")
     a = ap.parse_args()
     changes = {}
@@ -44,6 +45,8 @@ def main():
         changes["hip_stem"] = False
     if a.no_hip_conv1x1:
         changes["hip_conv1x1"] = False
+    if a.no_linear_terms:
+        changes["linear_terms_min_rows"] = 0
     if a.fused_small:
         changes["fused_small_maps"] = True
     dev = torch.device("cuda:0")
