@@ -60,7 +60,9 @@ SYMBOLS = {
     "mirx_linear_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_rows_to_terms": (_int, [_vp, _i64, _int, _i64, ctypes.c_float, _vp, _vp]),
     "mirx_layernorm_terms": (_int, [_vp, _i64, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
-    "mirx_linear_terms": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp]),
+    "mirx_linear_terms": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _i64,
+                                 _vp]),
+    "mirx_linear_terms_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mirx_linear_split3": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split2h_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,

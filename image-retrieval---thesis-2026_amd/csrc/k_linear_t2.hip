@@ -54,40 +54,99 @@ __device__ unsigned long long g_lt2_stamps[4096 * 8];      // per workgroup (mod
 #endif
 
 // ACT: 0 none, 1 GELU (erf), 2 GELU (tanh).  RES: y = res + gamma * v.  TOUT: the result is written as terms rows.
+// The epilogue of four consecutive outputs `col ..` of token `row` (v = raw accumulators): shared by the tile kernel and by
+// the fix-up kernel of split tiles, so that both round identically.
+template <int ACT, bool RES, bool TOUT>
+__device__ inline void finish4(f32x4 v, int64_t row, int col, const f32x4 &bv, const f32x4 &gv, float out_scale, int n,
+                               const float *res, float *y, char *yt, float y_scale, int np) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = v[e] * out_scale + bv[e];
+        if (!(MIRX_LT2_EXP & 4)) {
+            if (ACT == 1) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+            if (ACT == 2) t = gelu_tanh(t);
+        }
+        v[e] = t;
+    }
+    if (RES && !(MIRX_LT2_EXP & 4)) {
+        const f32x4 r = *reinterpret_cast<const f32x4 *>(res + row * n + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = r[e] + gv[e] * v[e];
+    }
+    if (TOUT) {
+        unsigned h0, l0, h1, l1;
+        split2h_pair(v[0] * y_scale, v[1] * y_scale, h0, l0);
+        split2h_pair(v[2] * y_scale, v[3] * y_scale, h1, l1);
+        const u32x2 hi = {h0, h1}, lo = {l0, l1};
+        char *dst = yt + row * ((int64_t)np * 4) + (col >> 5) * LINE + (col & 31) * 2;
+        *reinterpret_cast<u32x2 *>(dst) = hi;
+        *reinterpret_cast<u32x2 *>(dst + 64) = lo;
+    } else {
+        *reinterpret_cast<f32x4 *>(y + row * n + col) = v;
+    }
+}
+
+// TAIL SPLIT.  One tile occupies one CU for its whole K loop, so a launch of T tiles on P CUs takes ceil(T / P) rounds: 516
+// tiles on 256 CUs (DINOv2's proj at 32 images) run as long as 768 would.  The launcher therefore runs only the first
+// floor(T / P) * P tiles whole ("plain"); each of the r remaining tiles is cut along K into `parts` = min(stages, P / r) pieces
+// that run side by side as the launch's last, short round, store their raw accumulators into `ws` [r * parts][256][256] and are
+// summed (in piece order: deterministic) and finished by k_linear_t2_fix.  parts == 1 means no split.
 template <int ACT, bool RES, bool TOUT>
 __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ xt, int64_t m, int kp,
                                                       const char *__restrict__ wt, const float *__restrict__ bias, int n,
                                                       const float *res, const float *__restrict__ gamma, float out_scale,
                                                       float *y, char *yt, float y_scale, int np, int ntn,
-                                                      int64_t total_tiles, int64_t per_xcd) {
+                                                      int64_t plain_tiles, int64_t per_xcd, int parts, float *ws) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= total_tiles) return;
+    // workgroups [0, 8 per_xcd): plain tiles, dealt so that each XCD gets a contiguous run of them; beyond: pieces of the
+    // split tiles
+    int64_t tile;
+    int piece = -1;
+    if (blockIdx.x < 8 * per_xcd) {
+        tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (tile >= plain_tiles) return;
+    } else {
+        piece = (int)(blockIdx.x - 8 * per_xcd);
+        tile = plain_tiles + piece / parts;
+    }
     const int tn = (int)(tile % ntn);
     const int64_t m0 = (tile / ntn) * TM;
     const int n0 = tn * TN;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wtok = wave >> 2, wout = wave & 3;              // this wave: tokens 128 wtok .., outputs 64 wout ..
-    const int nk = kp >> 5;
     const int pitch = kp * 4;                                 // bytes of a terms row
+    int k_first = 0, nk = kp >> 5;                            // this workgroup's stages: [k_first, k_first + nk)
+    if (piece >= 0) {
+        const int p = piece % parts, all = kp >> 5;
+        k_first = (int)((int64_t)p * all / parts);
+        nk = (int)((int64_t)(p + 1) * all / parts) - k_first;
+    }
 
-    // ---- DMA addressing: piece p = tile rows 8 p .. 8 p + 7 (1 KiB); wave w moves pieces w, w + 8, w + 16, w + 24 of each
-    // operand.  Lane l: row 8 p + (l >> 3), LDS slot l & 7 <- source chunk (l & 7) ^ ((row >> 1) & 7).  Rows beyond the
-    // matrix are outside the descriptor: they read as zero.
-    const int prow = wave * 8 + (lane >> 3);
+    // ---- DMA addressing: piece p = tile rows 8 p .. 8 p + 7 (1 KiB).  Only waves 0-3 move data: wave w owns pieces w,
+    // w + 4, .. w + 28 of each operand (see ROLES below).  Lane l: row 8 p + (l >> 3), LDS slot l & 7 <- source chunk
+    // (l & 7) ^ ((row >> 1) & 7).  Rows beyond the matrix are outside the descriptor: they read as zero.
+    const int grp = wave >> 2;
+    const int prow = (wave & 3) * 8 + (lane >> 3);
     const int pchunk = (lane & 7) ^ ((prow >> 1) & 7);
-    int vo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vo[i] = (prow + 64 * i) * pitch + pchunk * 16;
+    const int vo0 = prow * pitch + pchunk * 16;               // piece i of this wave: + i * 32 rows
     const int64_t rows_here = m - m0 < TM ? m - m0 : TM;
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(xt + m0 * pitch), 0, (int)rows_here * pitch, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(wt + (int64_t)n0 * pitch), 0, TN * pitch, 0x00020000);
-#define DMA_X(BUF, I, KT) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, LDS_PTR(sm + (BUF) * STAGE + ((I) * 8 + wave) * 1024), 16, vo[I], (KT) * LINE, 0, 0)
-#define DMA_W(BUF, I, KT) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, LDS_PTR(sm + (BUF) * STAGE + X_BYTES + ((I) * 8 + wave) * 1024), 16, vo[I], (KT) * LINE, 0, 0)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(xt + m0 * pitch + k_first * LINE), 0, (int)rows_here * pitch - k_first * LINE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(wt + (int64_t)n0 * pitch + k_first * LINE), 0, TN * pitch - k_first * LINE, 0x00020000);
+    // one stage (both operands) into buffer BUF: 16 pieces of this wave, back to back
+#define DMA_STAGE(BUF, KT)                                                                                             \
+    {                                                                                                                  \
+        int vo_ = vo0;                                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, LDS_PTR(sm + (BUF) * STAGE + (i_ * 4 + (wave & 3)) * 1024), 16, vo_, \
+                                                     (KT) * LINE, 0, 0);                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, LDS_PTR(sm + (BUF) * STAGE + X_BYTES + (i_ * 4 + (wave & 3)) * 1024), \
+                                                     16, vo_, (KT) * LINE, 0, 0);                                      \
+            vo_ += 32 * pitch;                                                                                         \
+            asm volatile("" : "+v"(vo_)); /* one running offset, not eight live ones */                                 \
+        }                                                                                                              \
+    }
 
     // ---- fragment addressing: lane -> row (lane & 15), chunk (lane >> 4) of the term; lo = hi ^ 64 ------------------
     const int sw = (lane & 15) >> 1;
@@ -184,50 +243,34 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
         P1_READ(BUF, 6) P1_MUL(3)                                               \
         P1_READ(BUF, 7) P1_MUL(4)                                               \
     }
-    // A DMA piece stalls the issuing wave for 60-180 cycles (MI355X_MICROARCH.md): the eight pieces a wave owns go into
-    // eight gaps of PART2's MFMA stream, and the two waves that share a SIMD (w and w + 4) use alternate gaps, so that one of
-    // them feeds the matrix pipe while the other stalls.
-#define GAP(G, I, BUF, KT)                                                      \
-    if (more && grp == (G)) {                                                   \
-        DMA_X(BUF, I, (KT) + 2);                                                \
-        DMA_W(BUF, I, (KT) + 2);                                                \
-    }
+    // ROLES.  A DMA piece stalls the issuing wave for 60-180 cycles (MI355X_MICROARCH.md), and right after the barrier every
+    // wave wants to issue its pieces: with the pieces spread over all eight waves, both waves of a SIMD stall together and the
+    // matrix pipe idles (measured: 3 975 cycles per stage for 3 072 of MFMA work).  So the two waves of a SIMD (w and w + 4)
+    // get different jobs for the time after the barrier: wave w + 4 (raised priority) multiplies straight on -- PART2, then
+    // PART1 of the next stage -- while wave w first issues ALL of the SIMD pair's DMA (16 pieces back to back, stalling
+    // beside its partner's MFMAs) and multiplies afterwards, when the partner waits at the next barrier.
 #define PART2(BUF, KT)                                                          \
     {                                                                           \
         const bool more = DMA_ON && (KT) + 2 < nk;                              \
         KBARRIER();                                                             \
         FENCE();                                                                \
-        T3(0, 5)                                                                \
         fx[0][0] = LDX((BUF) ^ 1, 0, 0);                                        \
         fx[0][1] = LDX((BUF) ^ 1, 0, 1);                                        \
-        GAP(0, 0, BUF, KT)                                                      \
+        if (more && grp == 0) DMA_STAGE(BUF, (KT) + 2)                          \
         FENCE();                                                                \
-        T3(0, 6)                                                                \
-        GAP(1, 0, BUF, KT)                                                      \
+        T3(0, 5) T3(0, 6) T3(0, 7)                                              \
         FENCE();                                                                \
-        T3(0, 7) T3(1, 5)                                                       \
-        GAP(0, 1, BUF, KT)                                                      \
-        FENCE();                                                                \
-        T3(1, 6)                                                                \
+        T3(1, 5) T3(1, 6)                                                       \
         fw[0][0] = LDW((BUF) ^ 1, 0, 0);                                        \
         fw[0][1] = LDW((BUF) ^ 1, 0, 1);                                        \
-        GAP(1, 1, BUF, KT)                                                      \
         FENCE();                                                                \
-        T3(1, 7) T3(2, 5)                                                       \
-        GAP(0, 2, BUF, KT)                                                      \
-        FENCE();                                                                \
-        T3(2, 6)                                                                \
+        T3(1, 7) T3(2, 5) T3(2, 6)                                              \
         fw[1][0] = LDW((BUF) ^ 1, 1, 0);                                        \
         fw[1][1] = LDW((BUF) ^ 1, 1, 1);                                        \
-        GAP(1, 2, BUF, KT)                                                      \
         FENCE();                                                                \
-        T3(2, 7) T3(3, 5)                                                       \
-        GAP(0, 3, BUF, KT)                                                      \
-        FENCE();                                                                \
-        T3(3, 6)                                                                \
+        T3(2, 7) T3(3, 5) T3(3, 6)                                              \
         fw[2][0] = LDW((BUF) ^ 1, 2, 0);                                        \
         fw[2][1] = LDW((BUF) ^ 1, 2, 1);                                        \
-        GAP(1, 3, BUF, KT)                                                      \
         FENCE();                                                                \
         T3(3, 7)                                                                \
         FENCE();                                                                \
@@ -238,20 +281,10 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
     }
 
     // ---- prologue: stages 0 and 1 in flight, the first fragments of stage 0 in registers ----------------------------
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        DMA_X(0, i, 0);
-        DMA_W(0, i, 0);
-    }
+    if (grp == 0) DMA_STAGE(0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            DMA_X(1, i, 1);
-            DMA_W(1, i, 1);
-        }
-    }
+    if (grp == 0 && nk > 1) DMA_STAGE(1, 1)
 #pragma unroll
     for (int oi = 0; oi < 4; ++oi) {
         fw[oi][0] = LDWR(0, oi, 0);
@@ -264,7 +297,6 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
     }
     // waves 4-7 are the younger partners on their SIMDs and lose the issue arbitration against waves 0-3, which then wait for
     // them at every barrier: a static priority evens the two out (k_gemm.hip)
-    const int grp = wave >> 2;
     if (grp) __builtin_amdgcn_s_setprio(3);
 
 #if MIRX_LT2_EXP & 32
@@ -291,20 +323,28 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
 #undef PART2
 #undef P1_READ
 #undef P1_MUL
-#undef GAP
 #undef DMA_ON
+#undef DMA_STAGE
 #undef T3
 #undef LDX
 #undef LDW
 #undef LDXR
 #undef LDWR
-#undef DMA_X
-#undef DMA_W
 
 #if MIRX_LT2_EXP & 32
     const unsigned long long cy1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- epilogue straight from the accumulators: a lane holds 4 consecutive outputs of one token per tile --------------
+    if (piece >= 0) {                                        // a piece of a split tile: raw sums -> ws[piece][token][output]
+        float *wp = ws + (int64_t)piece * (TM * TN);
+#pragma unroll
+        for (int oi = 0; oi < 4; ++oi)
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti)
+                *reinterpret_cast<f32x4 *>(wp + (wtok * 128 + 16 * ti + (lane & 15)) * TN + wout * 64 + 16 * oi + 4 * (lane >> 4)) =
+                    acc[oi][ti];
+        return;
+    }
     const int colmax = TOUT ? np : n;
 #pragma unroll
     for (int oi = 0; oi < 4; ++oi) {
@@ -317,32 +357,7 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
         for (int ti = 0; ti < 8; ++ti) {
             const int64_t row = m0 + wtok * 128 + 16 * ti + (lane & 15);
             if (row >= m) continue;
-            f32x4 v = acc[oi][ti];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = v[e] * out_scale + bv[e];
-                if (!(MIRX_LT2_EXP & 4)) {
-                    if (ACT == 1) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
-                    if (ACT == 2) t = gelu_tanh(t);
-                }
-                v[e] = t;
-            }
-            if (RES && !(MIRX_LT2_EXP & 4)) {
-                const f32x4 r = *reinterpret_cast<const f32x4 *>(res + row * n + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = r[e] + gv[e] * v[e];
-            }
-            if (TOUT) {
-                unsigned h0, l0, h1, l1;
-                split2h_pair(v[0] * y_scale, v[1] * y_scale, h0, l0);
-                split2h_pair(v[2] * y_scale, v[3] * y_scale, h1, l1);
-                const u32x2 hi = {h0, h1}, lo = {l0, l1};
-                char *dst = yt + row * ((int64_t)np * 4) + (col >> 5) * LINE + (col & 31) * 2;
-                *reinterpret_cast<u32x2 *>(dst) = hi;
-                *reinterpret_cast<u32x2 *>(dst + 64) = lo;
-            } else {
-                *reinterpret_cast<f32x4 *>(y + row * n + col) = v;
-            }
+            finish4<ACT, RES, TOUT>(acc[oi][ti], row, col, bv, gv, out_scale, n, res, y, yt, y_scale, np);
         }
     }
 #if MIRX_LT2_EXP & 32
@@ -359,6 +374,38 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
         o[7] = st_p2;
     }
 #endif
+}
+
+// Split tiles: sum the `parts` pieces of tile `plain_tiles + blockIdx.x / 16` (piece order) and finish them.  One workgroup =
+// 16 token rows x 256 outputs; thread -> 4 consecutive outputs, 4 rows.
+template <int ACT, bool RES, bool TOUT>
+__global__ __launch_bounds__(256) void k_linear_t2_fix(const float *__restrict__ ws, int parts, int64_t plain_tiles, int ntn,
+                                                       int64_t m, const float *__restrict__ bias, int n, const float *res,
+                                                       const float *__restrict__ gamma, float out_scale, float *y, char *yt,
+                                                       float y_scale, int np) {
+    const int64_t st = blockIdx.x >> 4;
+    const int64_t tile = plain_tiles + st;
+    const int n0 = (int)(tile % ntn) * TN;
+    const int64_t m0 = (tile / ntn) * TM;
+    const int col = n0 + 4 * (threadIdx.x & 63);
+    if (col >= (TOUT ? np : n)) return;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+    if (bias && col < n) bv = *reinterpret_cast<const f32x4 *>(bias + col);
+    if (RES && gamma) gv = *reinterpret_cast<const f32x4 *>(gamma + col);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = (blockIdx.x & 15) * 16 + (threadIdx.x >> 6) + 4 * j;
+        const int64_t row = m0 + rl;
+        if (row >= m) continue;
+        const float *src = ws + st * parts * (int64_t)(TM * TN) + rl * TN + 4 * (threadIdx.x & 63);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+        for (int p = 1; p < parts; ++p) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + p * (int64_t)(TM * TN));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += a[e];
+        }
+        finish4<ACT, RES, TOUT>(v, row, col, bv, gv, out_scale, n, res, y, yt, y_scale, np);
+    }
 }
 
 // fp32 rows [m][k] (row stride ldx floats) -> terms rows [m][kp / 32] lines, scaled by the power of two `scale`.
@@ -408,18 +455,60 @@ hipError_t launch_rows_to_terms(const float *x, int64_t m, int k, int64_t ldx, f
     return hipGetLastError();
 }
 
+// how a launch of `tiles` tiles is cut on `cus` CUs (see TAIL SPLIT above): plain tiles, split tiles, pieces per split tile
+static void lt2_plan(int64_t tiles, int stages, int cus, int64_t *plain, int64_t *split, int *parts) {
+    *plain = tiles / cus * cus;
+    *split = tiles - *plain;
+    int64_t g = *split > 0 ? cus / *split : 1;
+    if (g > stages) g = stages;
+    if (g < 2) {                      // the last round is more than half full (or there is none): whole tiles
+        *plain = tiles;
+        *split = 0;
+        g = 1;
+    }
+    *parts = (int)g;
+}
+
+static int lt2_cus() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu = v > 0 ? v : 256;
+    }
+    return ncu;
+}
+
+size_t linear_t2_workspace_bytes(int64_t m, int k, int n) {
+    if (m <= 0 || k < 1 || n < 1) return 0;
+    int64_t plain, split;
+    int parts;
+    lt2_plan(((m + TM - 1) / TM) * ((n + TN - 1) / TN), (k + 31) / 32, lt2_cus(), &plain, &split, &parts);
+    return (size_t)(split * parts) * TM * TN * sizeof(float);
+}
+
 hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, const float *bias, int n, int act,
                             const float *res, const float *gamma, float out_scale, float *y, void *yt, float y_scale,
-                            hipStream_t st) {
+                            void *workspace, size_t workspace_bytes, hipStream_t st) {
     if (m <= 0) return hipSuccess;
     if (k < 1 || n < 4 || (n & 3) || act < 0 || act > 2 || (!y && !yt) || (y && yt) || (yt && res) || (gamma && !res))
         return hipErrorInvalidValue;
     const int kp = (k + 31) / 32 * 32, np = (n + 31) / 32 * 32;
     const int ntn = (n + TN - 1) / TN;                 // wt holds ntn * 256 rows, zero beyond n
     const int64_t total = ((m + TM - 1) / TM) * ntn;
-    const int64_t per_xcd = (total + 7) / 8;
-    if (per_xcd * 8 > 0x7fffffff || (int64_t)TM * kp * 4 > 0x7fffffff) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(per_xcd * 8));
+    int64_t plain, split;
+    int parts;
+    lt2_plan(total, kp / 32, lt2_cus(), &plain, &split, &parts);
+    if (split > 0 && (!workspace || workspace_bytes < (size_t)(split * parts) * TM * TN * sizeof(float))) {
+        plain = total;                                 // no (or too small a) workspace: whole tiles only
+        split = 0;
+        parts = 1;
+    }
+    const int64_t per_xcd = (plain + 7) / 8;
+    const int64_t blocks = per_xcd * 8 + split * parts;
+    if (blocks > 0x7fffffff || (int64_t)TM * kp * 4 > 0x7fffffff) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    float *ws = reinterpret_cast<float *>(workspace);
 #define MIRX_T2(A, R, T)                                                                                               \
     {                                                                                                                  \
         static bool attr_set = false;                                                                                  \
@@ -431,7 +520,10 @@ hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, co
         }                                                                                                              \
         hipLaunchKernelGGL((k_linear_t2<A, R, T>), grid, dim3(512), LDS_BYTES, st, reinterpret_cast<const char *>(xt), m, kp, \
                            reinterpret_cast<const char *>(wt), bias, n, res, gamma, out_scale, y,                      \
-                           reinterpret_cast<char *>(yt), y_scale, np, ntn, total, per_xcd);                            \
+                           reinterpret_cast<char *>(yt), y_scale, np, ntn, plain, per_xcd, parts, ws);                 \
+        if (split > 0)                                                                                                 \
+            hipLaunchKernelGGL((k_linear_t2_fix<A, R, T>), dim3((unsigned)(split * 16)), dim3(256), 0, st, ws, parts, plain, ntn, \
+                               m, bias, n, res, gamma, out_scale, y, reinterpret_cast<char *>(yt), y_scale, np);       \
     }
     if (yt) {
         if (act == 2) MIRX_T2(2, false, true) else if (act == 1) MIRX_T2(1, false, true) else MIRX_T2(0, false, true)

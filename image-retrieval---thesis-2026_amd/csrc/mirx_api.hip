@@ -907,9 +907,11 @@ int mirx_rows_to_terms(const float *x, int64_t m, int k, int64_t row_stride, flo
     return MIRX_OK;
 }
 
+int64_t mirx_linear_terms_workspace_bytes(int64_t m, int k, int n) { return (int64_t)linear_t2_workspace_bytes(m, k, n); }
+
 int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const float *bias_or_null, int n, int act,
                       const float *residual_or_null, const float *gamma_or_null, float out_scale, float *y_or_null,
-                      void *yt_or_null, float yt_scale, void *stream) {
+                      void *yt_or_null, float yt_scale, void *workspace_or_null, int64_t workspace_bytes, void *stream) {
     MIRX_CHECK(m >= 0 && k >= 1 && n >= 4 && n % 4 == 0, "linear_terms: n must be a multiple of 4");
     MIRX_CHECK(act >= 0 && act <= 2, "linear_terms: act is 0 (none), 1 (GELU) or 2 (tanh GELU)");
     MIRX_CHECK(m == 0 || (xt && wt), "linear_terms: null operand");
@@ -918,8 +920,10 @@ int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const fl
     MIRX_CHECK(!(residual_or_null && act), "linear_terms: the residual form has no activation");
     MIRX_CHECK(!gamma_or_null || residual_or_null, "linear_terms: gamma scales the residual form only");
     MIRX_CHECK(!yt_or_null || yt_scale > 0.f, "linear_terms: yt_scale must be positive");
+    MIRX_CHECK(workspace_bytes >= 0, "linear_terms: negative workspace size");
     MIRX_HIP(launch_linear_t2(xt, m, k, wt, bias_or_null, n, act, residual_or_null, gamma_or_null, out_scale, y_or_null,
-                              yt_or_null, yt_scale, reinterpret_cast<hipStream_t>(stream)));
+                              yt_or_null, yt_scale, workspace_or_null, workspace_or_null ? (size_t)workspace_bytes : 0,
+                              reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

@@ -124,7 +124,8 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
 hipError_t launch_rows_to_terms(const float *x, int64_t m, int k, int64_t ldx, float scale, void *xt, hipStream_t st);
 hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, const float *bias, int n, int act,
                             const float *res, const float *gamma, float out_scale, float *y, void *yt, float y_scale,
-                            hipStream_t st);
+                            void *workspace, size_t workspace_bytes, hipStream_t st);
+size_t linear_t2_workspace_bytes(int64_t m, int k, int n);
 hipError_t launch_patchify(const float *x, int64_t n, int c, int h, int w, int p, const float *gamma, const float *beta,
                            float eps, float *out, int kpad, hipStream_t st);
 hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, const float *v, int64_t kv_rs,

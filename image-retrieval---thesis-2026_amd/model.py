@@ -100,6 +100,7 @@ class KernelConfig:
     conv3x3_legacy: tuple = ((56, "wino"), (28, "wino3"), (14, "direct3"), (7, "wino"))
     linear_three_bf16: bool = True          # token-major Linears on the MFMA kernels at all (False: rocBLAS fp32)
     linear_two_fp16: bool = True            #   .. on two fp16 terms where the input has a provable bound (LayerNorm outputs)
+    linear_terms_split_tail: bool = True    #   .. its last, partly filled round of tiles cut along K (mirx.h, mirx_linear_terms workspace)
     linear_terms_min_rows: int = 4096       #   .. ViT / SigLIP blocks with at least this many token rows: the DMA-fed Linear on pre-split
                                             #      "terms rows" (k_linear_t2: 256 x 256 tiles); 0 = never
     attention_three_bf16: bool = True       # flash attention on three bf16 terms (False: fp32 MFMAs)
@@ -640,13 +641,17 @@ def _linear_terms(mod, xt, xs, lead, act=0, res=None, gamma=None, out=None, term
         out = torch.empty(tuple(lead) + (n,), dtype=torch.float32, device=dev)
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
+    lib = _lib.load()
+    wsb = int(lib.mirx_linear_terms_workspace_bytes(m, mod.in_features, n)) if _cfg(mod).linear_terms_split_tail else 0
+    wsp = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None         # stream-ordered: safe across streams
     with torch.cuda.device(dev):
         _lib.check(_lib.load().mirx_linear_terms(_ptr(xt), m, mod.in_features, _ptr(wt),
                                                  _ptr(mod.bias.detach()) if mod.bias is not None else None, n, act,
                                                  _ptr(res) if res is not None else None,
                                                  _ptr(gamma.detach()) if gamma is not None else None, 1.0 / (xs * ws),
                                                  _ptr(out) if yt is None else None, _ptr(yt) if yt is not None else None,
-                                                 ys if ys is not None else 1.0, _stream(dev)), "mirx_linear_terms")
+                                                 ys if ys is not None else 1.0, _ptr(wsp) if wsp is not None else None, wsb,
+                                                 _stream(dev)), "mirx_linear_terms")
     return (yt, ys) if yt is not None else out
 
 

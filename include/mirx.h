@@ -350,13 +350,19 @@ int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const 
  *                       y (fp32 [m][n]) = v, or residual + gamma[j] * v (act 0; gamma NULL = 1; y may alias residual);
  *                       or yt = terms rows of yt_scale * v (no residual) -- the next Linear's input, written in full lines.
  *                       wt = terms rows of W * w scale, ceil(n / 256) * 256 rows (zero beyond n).  n % 4 == 0.
+ *                       workspace: a tile (256 tokens x 256 outputs) occupies one CU for its whole K loop, so a launch whose
+ *                       tile count is not a multiple of the CU count would end in a mostly empty round.  With a device
+ *                       buffer of mirx_linear_terms_workspace_bytes(m, k, n) bytes (0 = not needed; at most 64 MiB) the
+ *                       tiles of that last round are cut along k into pieces that run side by side and are summed in piece
+ *                       order by a second launch -- deterministic for a given (m, k, n).  NULL = whole tiles only.
  */
 int mirx_rows_to_terms(const float *x, int64_t m, int k, int64_t row_stride, float scale, void *xt, void *stream);
 int mirx_layernorm_terms(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
                          float scale, void *yt, void *stream);
 int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const float *bias_or_null, int n, int act,
                       const float *residual_or_null, const float *gamma_or_null, float out_scale, float *y_or_null,
-                      void *yt_or_null, float yt_scale, void *stream);
+                      void *yt_or_null, float yt_scale, void *workspace_or_null, int64_t workspace_bytes, void *stream);
+int64_t mirx_linear_terms_workspace_bytes(int64_t m, int k, int n);
 
 /*
  * Tail of a ConvNeXtV2 block (timm ConvNeXtBlock.forward, used by the reference's model.py:87-118): the second

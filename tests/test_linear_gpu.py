@@ -335,14 +335,15 @@ def test_rows_to_terms_and_layernorm_terms(m, k):
 
 
 @pytest.mark.parametrize("m,k,n", [(1, 32, 4), (300, 96, 200), (255, 200, 96), (257, 768, 2304), (1370 * 2 + 5, 768, 768),
-                                   (513, 3072, 768), (260, 1152, 4304), (300, 4304, 1152), (4100, 64, 516)])
+                                   (513, 3072, 768), (260, 1152, 4304), (300, 4304, 1152), (4100, 64, 516), (5120, 96, 3328)])
 @pytest.mark.parametrize("act,use_res,use_gamma,terms_out", [(0, False, False, False), (1, False, False, False),
                                                              (2, False, False, True), (0, True, True, False),
                                                              (0, True, False, False), (1, False, False, True)])
 def test_linear_terms_matches_float64(m, k, n, act, use_res, use_gamma, terms_out):
     """mirx_linear_terms (csrc/k_linear_t2.hip: both operands pre-split, DMA-fed 256 x 256 tiles) against a float64
-    restatement -- ragged token / output / feature counts, every epilogue, the terms-rows output -- and against
-    mirx_linear_split2h, whose arithmetic it shares (same tolerance class: 3e-6 of the largest |y|)."""
+    restatement -- ragged token / output / feature counts, every epilogue, the terms-rows output; tile counts below the CU
+    count (every tile cut along k), and 260 tiles (256 whole + 4 cut ones).  Tolerance class of mirx_linear_split2h, whose
+    arithmetic it shares: 3e-6 of the largest |y|."""
     import mirx.model as mm
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(m * 3 + k + n + act)
@@ -391,15 +392,37 @@ def test_linear_terms_argument_checks():
     y = torch.zeros(4, 8, device=dev)
     f = ctypes.c_float
     ok = lambda *a: lib.mirx_linear_terms(*a) == 0       # noqa: E731
-    assert ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 6, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)          # n % 4
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 3, None, None, f(1.0), _vp(y), None, f(1.0), None)          # act
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), None, None, f(1.0), None)            # no output
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), _vp(xt), f(1.0), None)       # two outputs
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 1, _vp(y), None, f(1.0), _vp(y), None, f(1.0), None)        # residual + activation
-    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, _vp(y), f(1.0), _vp(y), None, f(1.0), None)        # gamma without residual
-    assert ok(_vp(xt), 0, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None)              # empty batch
+    assert ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None, 0, None)
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 6, 0, None, None, f(1.0), _vp(y), None, f(1.0), None, 0, None)          # n % 4
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 3, None, None, f(1.0), _vp(y), None, f(1.0), None, 0, None)          # act
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), None, None, f(1.0), None, 0, None)            # no output
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), _vp(xt), f(1.0), None, 0, None)       # two outputs
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 1, _vp(y), None, f(1.0), _vp(y), None, f(1.0), None, 0, None)        # residual + activation
+    assert not ok(_vp(xt), 4, 32, _vp(wt), None, 8, 0, None, _vp(y), f(1.0), _vp(y), None, f(1.0), None, 0, None)        # gamma without residual
+    assert ok(_vp(xt), 0, 32, _vp(wt), None, 8, 0, None, None, f(1.0), _vp(y), None, f(1.0), None, 0, None)              # empty batch
     assert lib.mirx_rows_to_terms(_vp(y), 4, 8, 6, f(1.0), _vp(xt), None) != 0                                   # row_stride < k
+
+
+def test_linear_terms_tail_split_agrees_with_whole_tiles():
+    """The cut tiles of the last round (workspace + fix-up launch) against the same launch on whole tiles only."""
+    import mirx.model as mm
+    from mirx import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    m, k, n = 5120, 768, 3328                                    # 20 x 13 = 260 tiles: 256 whole, 4 cut into 24 pieces each
+    assert _lib.load().mirx_linear_terms_workspace_bytes(m, k, n) == 4 * 24 * 256 * 256 * 4
+    assert _lib.load().mirx_linear_terms_workspace_bytes(256 * 16, k, 256 * 16) == 0       # 256 tiles: nothing to cut
+    lin = torch.nn.Linear(k, n).to(dev)
+    x = torch.randn(m, k, device=dev).clamp_(-5, 5)
+    with torch.no_grad():
+        xt, xs = mm._rows_to_terms(x, 5.0)
+        a = mm._linear_terms(lin, xt, xs, (m,), act=1)
+        mm.set_kernel_config(lin, dataclasses.replace(mm.DEFAULT_CONFIG, linear_terms_split_tail=False))
+        b = mm._linear_terms(lin, xt, xs, (m,), act=1)
+        a2 = mm._linear_terms(lin, xt, xs, (m,), act=1)
+    assert float((a - b).abs().max()) < 1e-6 * float(b.abs().max())
+    assert torch.equal(b, a2)                                    # whole tiles: run to run identical
+    assert torch.equal(a[: 19 * 256], b[: 19 * 256])             # rows whose tiles were not cut are the same bits
 
 
 def test_vit_block_terms_path_matches_split2h_path():
