@@ -101,7 +101,7 @@ class KernelConfig:
     linear_three_bf16: bool = True          # token-major Linears on the MFMA kernels at all (False: rocBLAS fp32)
     linear_two_fp16: bool = True            #   .. on two fp16 terms where the input has a provable bound (LayerNorm outputs)
     linear_terms_split_tail: bool = True    #   .. its last, partly filled round of tiles cut along K (mirx.h, mirx_linear_terms workspace)
-    linear_terms_min_rows: int = 4096       #   .. ViT / SigLIP blocks with at least this many token rows: the DMA-fed Linear on pre-split
+    linear_terms_min_rows: int = 1024       #   .. ViT / SigLIP blocks with at least this many token rows: the DMA-fed Linear on pre-split
                                             #      "terms rows" (k_linear_t2: 256 x 256 tiles); 0 = never
     attention_three_bf16: bool = True       # flash attention on three bf16 terms (False: fp32 MFMAs)
     attention_two_fp16: bool = True         #   .. on two fp16 terms where q / k / v have provable bounds
