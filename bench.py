@@ -357,11 +357,12 @@ def extras(args, dev):
         m = ctor().eval().to(dev)
         x = synthetic_images(batch, size, 99, dev)
         ips = timed_images_per_s(m, x, iters)
+        one = 1e3 / timed_images_per_s(m, x[:1].contiguous(), 10, warmup=3)        # the reference's per-query loop: one image per call
         flop, nbytes = work[name]
         tr, tr_file = profile_traffic(name, "bytes_per_image")
         tr_batch, _ = profile_traffic(name, "batch")
         f_frac, b_frac = flop * ips / 1e12 / FP32_EQ_PEAK_TFLOPS, nbytes * ips / 1e9 / 8000.0
-        out[name] = {"images_per_s": ips, "batch": batch, "image_size": size, "dtype": "f32 (two fp16 / three bf16 MFMA terms)",
+        out[name] = {"images_per_s": ips, "batch": batch, "single_image_ms": one, "image_size": size, "dtype": "f32 (two fp16 / three bf16 MFMA terms)",
                      "data": "synthetic images, random-init weights",
                      "algorithmic_gflop_per_image": flop / 1e9, "algorithmic_mb_per_image": nbytes / 1e6,
                      "roofline": {"bound": "mfma" if f_frac >= b_frac else "hbm", "frac_of_fp32_equivalent_mfma_peak": f_frac,
