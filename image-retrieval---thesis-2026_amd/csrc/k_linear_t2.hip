@@ -13,8 +13,10 @@
 //     stage as long as the fill's latency, 0.50-0.56 matrix-busy.  This tile needs 35 GB/s;
 //   * a stage is 32 features (one 128-byte line per row: 96 MFMAs per wave per barrier instead of 12), two 64-KiB LDS
 //     buffers, v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on this shape than on 32x32x16);
-//   * the barrier sits INSIDE a stage's MFMA stream, after the wave's last LDS read of the stage: the last quarter runs
-//     from registers while the DMA of the stage after next is issued and the next stage's first fragments are read.
+//   * the barrier sits INSIDE a stage's MFMA stream, after the wave's last LDS read of the stage (token tile 4 of 8): the
+//     rest runs from registers while the DMA of the stage after next is issued and the next stage's first fragments are read;
+//   * the two waves of a SIMD have different jobs after the barrier (ROLES below): one issues the pair's DMA, one multiplies;
+//   * a launch's last, partly filled round of tiles is cut along K (TAIL SPLIT below): also what fills the chip at small batches.
 //
 // TERMS ROWS: a [rows][K] matrix scaled by a power of two s, stored as rows of ceil(K / 32) lines of 128 bytes:
 //   line g of a row = fp16 hi(s x[32 g .. 32 g + 31]) | fp16 lo(..)   with hi = fp16(s x), lo = fp16(s x - hi)
