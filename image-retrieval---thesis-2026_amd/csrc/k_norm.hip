@@ -34,7 +34,9 @@ __device__ inline float wave_sum(float v) {
 // grid: ceil(m / 4) workgroups of 4 waves; wave w normalises row 4 * blockIdx.x + w.  c % 4 == 0.
 // TERMS: the result is written as "terms rows" (k_linear_t2.hip: line g of a row = fp16 hi | lo of scale * y[32 g .. 32 g + 31],
 // the input format of the DMA-fed Linear) instead of fp32 -- the same bytes, and the Linear that follows needs no split.
-template <bool TERMS>
+// The row is read ONCE and kept in registers (RV 16-byte vectors per lane: c <= 256 RV features; the launcher picks RV): mean,
+// variance (two passes over the registers, the reference's formula) and the result come from the same loads.
+template <bool TERMS, int RV>
 __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict__ x, int64_t m, int c,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float eps, float *__restrict__ y, char *__restrict__ yt, float scale,
@@ -44,29 +46,36 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict_
     if (row >= m) return;
     const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * c);
     const int nv = c >> 2;
+    f32x4 v[RV];
     float s = 0.f;
-    for (int i = lane; i < nv; i += 64) {
-        const f32x4 v = xr[i];
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int j = 0; j < RV; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < nv ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
     const float mean = wave_sum(s) / (float)c;
     float q = 0.f;
-    for (int i = lane; i < nv; i += 64) {               // second pass: the row is in L1 / L2
-        const f32x4 v = xr[i];
-        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int j = 0; j < RV; ++j) {
+        if (lane + 64 * j < nv) {
+            const float d0 = v[j][0] - mean, d1 = v[j][1] - mean, d2 = v[j][2] - mean, d3 = v[j][3] - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
     f32x4 *yr = reinterpret_cast<f32x4 *>(y + row * c);
     char *tr = yt + row * ((int64_t)cp * 4);
-    for (int i = lane; i < (TERMS ? cp >> 2 : nv); i += 64) {
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (!TERMS || i < nv) {
-            const f32x4 v = xr[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float g = gamma ? gamma[4 * i + j] : 1.f, b = beta ? beta[4 * i + j] : 0.f;
-                o[j] = (v[j] - mean) * rstd * g + b;
+    for (int j = 0; j < RV; ++j) {
+        const int i = lane + 64 * j;
+        if (i >= (TERMS ? cp >> 2 : nv)) continue;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = gamma ? gamma[4 * i + e] : 1.f, b = beta ? beta[4 * i + e] : 0.f;
+                o[e] = (v[j][e] - mean) * rstd * g + b;
             }
         }
         if (TERMS) {
@@ -243,8 +252,12 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
         if (tokens_per_image > 0 || y) return hipErrorInvalidValue;
         const int64_t blocks = (m + 3) / 4;
         if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_layernorm_rows<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, nullptr,
-                           reinterpret_cast<char *>(yt), scale, (c + 31) / 32 * 32);
+        const int cp = (c + 31) / 32 * 32;
+        if (cp > 8192) return hipErrorInvalidValue;
+#define MIRX_LNT(RV) hipLaunchKernelGGL((k_layernorm_rows<true, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
+                                        nullptr, reinterpret_cast<char *>(yt), scale, cp)
+        if (cp <= 512) MIRX_LNT(2); else if (cp <= 1024) MIRX_LNT(4); else if (cp <= 2048) MIRX_LNT(8); else if (cp <= 4096) MIRX_LNT(16); else MIRX_LNT(32);
+#undef MIRX_LNT
         return hipGetLastError();
     }
     if (tokens_per_image > 0) {
@@ -258,8 +271,11 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
     } else {
         const int64_t blocks = (m + 3) / 4;
         if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_layernorm_rows<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, y, nullptr,
-                           1.f, 0);
+        if (c > 8192) return hipErrorInvalidValue;
+#define MIRX_LN(RV) hipLaunchKernelGGL((k_layernorm_rows<false, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
+                                       y, nullptr, 1.f, 0)
+        if (c <= 512) MIRX_LN(2); else if (c <= 1024) MIRX_LN(4); else if (c <= 2048) MIRX_LN(8); else if (c <= 4096) MIRX_LN(16); else MIRX_LN(32);
+#undef MIRX_LN
     }
     return hipGetLastError();
 }

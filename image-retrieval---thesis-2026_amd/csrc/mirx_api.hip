@@ -878,7 +878,7 @@ int mirx_grn_scale(const float *gx, const float *weight, int64_t n, int c, float
 
 int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
                    float *y, int tokens_per_image, void *stream) {
-    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0, "layernorm: c must be a multiple of 4");
+    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0 && c <= 8192, "layernorm: c must be a multiple of 4, at most 8192");
     MIRX_CHECK(m == 0 || (x && y), "layernorm: null buffer");
     MIRX_CHECK(tokens_per_image >= 0 && (tokens_per_image == 0 || (c <= 512 && x != y)),
                "layernorm: the channels-first form needs c <= 512 and y != x");
@@ -890,7 +890,7 @@ int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null,
 
 int mirx_layernorm_terms(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
                          float scale, void *yt, void *stream) {
-    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0, "layernorm_terms: c must be a multiple of 4");
+    MIRX_CHECK(m >= 0 && c >= 4 && c % 4 == 0 && c <= 8160, "layernorm_terms: c must be a multiple of 4, at most 8160");
     MIRX_CHECK(m == 0 || (x && yt), "layernorm_terms: null buffer");
     MIRX_CHECK(eps >= 0.f && scale > 0.f, "layernorm_terms: eps must be non-negative and scale positive");
     MIRX_HIP(launch_layernorm_rows(x, m, c, gamma_or_null, beta_or_null, eps, nullptr, 0, reinterpret_cast<hipStream_t>(stream),

@@ -284,7 +284,7 @@ int mirx_stem_conv7_bn_relu_pool_split2h_into(const float *x, const void *w2, co
  * mirx_layernorm: y = (x - mean) / sqrt(var + eps) * gamma + beta over the last axis of x [m, c] (nn.LayerNorm inside
  *   timm ConvNeXtV2 / ViT and transformers SigLIP: model.py:96-100, 459-463, 553-557); biased variance, fp32.
  *   tokens_per_image == 0: y is [m, c] (may alias x); > 0: y is channels-first [m / tpi][c][tpi] (timm LayerNorm2d of the
- *   ConvNeXt stem; c <= 512, y != x).  c % 4 == 0.
+ *   ConvNeXt stem; c <= 512, y != x).  c % 4 == 0, c <= 8192 (a row lives in one wavefront's registers).
  * mirx_patchify_nchw: non-overlapping patch x patch blocks of x [n, c, h, w] as rows
  *   out[((b * (h/patch) + py) * (w/patch) + px) * row_stride + (ch * patch + ky) * patch + kx], columns beyond
  *   c * patch * patch zeroed: a Conv2d(c, cout, kernel = stride = patch) is patchify + mirx_linear_split3 / _split2h with
