@@ -90,6 +90,8 @@ SYMBOLS = {
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_attention_qkv_f32": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_attention_qkv_f32_split2h": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "mirx_attention_qkv_f32_split2h_terms": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                                    ctypes.c_float, _vp, _vp]),
     "mirx_attention_qkv_f32_split3": (_int, [_vp, _i64, _int, _int, _int, ctypes.c_float, _vp, _vp]),
     "mirx_l2_normalize": (_int, [_vp, _i64, _int, _vp]),
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
@@ -102,7 +104,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 301          # include/mirx.h MIRX_VERSION this binding was written against
+ABI_VERSION = 302          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():

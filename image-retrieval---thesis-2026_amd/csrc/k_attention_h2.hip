@@ -70,9 +70,22 @@ __device__ inline void attention_block(int &qt, int &head, int64_t &img) {
 #endif
 }
 
+// Four consecutive channels `ch ..` (ch % 4 == 0) of token row `row` written as "terms rows" (k_linear_t2.hip: per 32 features one
+// 128-byte line, fp16 high terms | fp16 low terms of scale * value): the input format of the DMA-fed Linear that follows.
+__device__ inline void store_terms4(char *out_t, int64_t row, int c, int ch, const f32x4 &v, float scale) {
+    unsigned h0, l0, h1, l1;
+    split2h_pair(v[0] * scale, v[1] * scale, h0, l0);
+    split2h_pair(v[2] * scale, v[3] * scale, h1, l1);
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+    const u32x2_ hi = {h0, h1}, lo = {l0, l1};
+    char *dst = out_t + row * ((int64_t)((c + 31) / 32 * 32) * 4) + (ch >> 5) * 128 + (ch & 31) * 2;
+    *reinterpret_cast<u32x2_ *>(dst) = hi;
+    *reinterpret_cast<u32x2_ *>(dst + 64) = lo;
+}
+
 __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict__ qkv, int n, int heads,
                                                          float q_mul, float k_mul, float v_mul, float s_inv, float o_inv,
-                                                         float *__restrict__ out) {
+                                                         float *__restrict__ out, char *__restrict__ out_t, float t_scale) {
     __shared__ __attribute__((aligned(16))) char sm[2 * BUF];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, nq = lane & 31;
@@ -241,7 +254,8 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
-                *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
+                if (out_t) store_terms4(out_t, (img * n + q_idx), heads * DH, head * DH + 4 * half + 32 * t + 8 * g, v, t_scale);
+                else *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
             }
     }
 }
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
 template <int DH>
 __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restrict__ qkv, int n, int heads, float q_mul,
                                                           float k_mul, float v_mul, float s_inv, float o_inv,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, char *__restrict__ out_t, float t_scale) {
     constexpr int KS = (DH + 15) / 16, KCH = 2 * KS, KROW = KCH * 16;      // K row: KCH chunks of 16 B
     constexpr int NT = (DH + 31) / 32;
     constexpr int KPL = KT * KROW, VPL = DH * 64, GBUF = 2 * (KPL + VPL);
@@ -461,43 +475,45 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g + j] * inv;
-                *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
+                if (out_t) store_terms4(out_t, (img * n + q_idx), heads * DH, head * DH + 4 * half + 32 * t + 8 * g, v, t_scale);
+                else *reinterpret_cast<f32x4 *>(op + 32 * t + 8 * g) = v;
             }
     }
 }
 
 template <int DH>
 hipError_t launch_h2g(const float *qkv, int64_t batch, int n, int heads, float q_mul, float k_mul, float v_mul, float s_inv,
-                      float o_inv, float *out, hipStream_t st) {
+                      float o_inv, float *out, char *out_t, float t_scale, hipStream_t st) {
     constexpr int KS = (DH + 15) / 16;
     const size_t lds = (size_t)2 * 2 * (KT * KS * 32 + DH * 64);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_h2g<DH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
-    hipLaunchKernelGGL(k_attention_h2g<DH>, grid, dim3(256), lds, st, qkv, n, heads, q_mul, k_mul, v_mul, s_inv, o_inv, out);
+    hipLaunchKernelGGL(k_attention_h2g<DH>, grid, dim3(256), lds, st, qkv, n, heads, q_mul, k_mul, v_mul, s_inv, o_inv, out, out_t, t_scale);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale,
-                               float qk_bound, float v_bound, float *out, hipStream_t st) {
+                               float qk_bound, float v_bound, float *out, hipStream_t st, void *out_terms, float terms_scale) {
     if (batch <= 0 || n <= 0) return hipSuccess;
     if (heads <= 0 || heads > 65535 || batch > 65535) return hipErrorInvalidValue;
     if (head_dim != DH && head_dim != 72 && head_dim != 96 && head_dim != 32) return hipErrorInvalidValue;
     if (!(qk_bound > 0.f) || !(v_bound > 0.f) || !(scale > 0.f)) return hipErrorInvalidValue;
+    if ((out != nullptr) == (out_terms != nullptr) || (heads * head_dim) % 4) return hipErrorInvalidValue;
     const float sl = scale * 1.4426950408889634f;
     // powers of two that bring each operand's bound to at most 2^14 (fp16 max 65504)
     const float qs = exp2f(floorf(log2f(16384.0f / (qk_bound * sl))));
     const float ks = exp2f(floorf(log2f(16384.0f / qk_bound)));
     const float vs = exp2f(floorf(log2f(16384.0f / v_bound)));
     const float s_inv = 1.0f / (qs * ks), o_inv = 1.0f / (1024.0f * vs);
-    if (head_dim == 72) return launch_h2g<72>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
-    if (head_dim == 96) return launch_h2g<96>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
-    if (head_dim == 32) return launch_h2g<32>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, st);
+    if (head_dim == 72) return launch_h2g<72>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, reinterpret_cast<char *>(out_terms), terms_scale, st);
+    if (head_dim == 96) return launch_h2g<96>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, reinterpret_cast<char *>(out_terms), terms_scale, st);
+    if (head_dim == 32) return launch_h2g<32>(qkv, batch, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, reinterpret_cast<char *>(out_terms), terms_scale, st);
     const dim3 grid((unsigned)((n + 127) / 128), (unsigned)heads, (unsigned)batch);
-    hipLaunchKernelGGL(k_attention_h2, grid, dim3(256), 0, st, qkv, n, heads, sl * qs, ks, vs, s_inv, o_inv, out);
+    hipLaunchKernelGGL(k_attention_h2, grid, dim3(256), 0, st, qkv, n, heads, sl * qs, ks, vs, s_inv, o_inv, out, reinterpret_cast<char *>(out_terms), terms_scale);
     return hipGetLastError();
 }
 

@@ -1022,6 +1022,20 @@ int mirx_attention_qkv_f32_split2h(const float *qkv, int64_t batch, int n_tokens
     return MIRX_OK;
 }
 
+int mirx_attention_qkv_f32_split2h_terms(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
+                                         float qk_bound, float v_bound, float out_scale, void *out_terms, void *stream) {
+    MIRX_CHECK(batch >= 0 && n_tokens >= 0 && heads >= 1, "attention_split2h_terms: bad sizes");
+    MIRX_CHECK(head_dim == 64 || head_dim == 72 || head_dim == 96 || head_dim == 32,
+               "attention_split2h_terms: head_dim must be 32, 64, 72 or 96");
+    MIRX_CHECK(batch <= 65535 && heads <= 65535, "attention_split2h_terms: batch and heads must be <= 65535");
+    MIRX_CHECK(batch == 0 || n_tokens == 0 || (qkv && out_terms), "attention_split2h_terms: null buffer");
+    MIRX_CHECK(qk_bound > 0.f && v_bound > 0.f && scale > 0.f && out_scale > 0.f,
+               "attention_split2h_terms: bounds and scales must be positive");
+    MIRX_HIP(launch_attention_h2(qkv, batch, n_tokens, heads, head_dim, scale, qk_bound, v_bound, nullptr,
+                                 reinterpret_cast<hipStream_t>(stream), out_terms, out_scale));
+    return MIRX_OK;
+}
+
 int mirx_rank_metrics(const int64_t *ranks, int64_t nq, int64_t n, int64_t row_stride,
                       const int64_t *gallery_labels, int64_t n_labels, const int64_t *query_labels,
                       const int64_t *query_ids_or_null, int drop_self, int rel_kind, double jaccard_threshold,

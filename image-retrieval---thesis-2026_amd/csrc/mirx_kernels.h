@@ -144,7 +144,7 @@ hipError_t launch_attention_s3(const float *qkv, int64_t batch, int n, int heads
                                hipStream_t st);
 // ---- k_attention_h2.hip: the same attention on two fp16 terms per operand (head_dim 64, caller-supplied bounds) --
 hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale,
-                               float qk_bound, float v_bound, float *out, hipStream_t st);
+                               float qk_bound, float v_bound, float *out, hipStream_t st, void *out_terms = nullptr, float terms_scale = 1.f);
 
 // ---- k_metrics.hip ----------------------------------------------------------------------
 constexpr int MIRX_MAX_KAPPAS = 8;

@@ -1428,12 +1428,22 @@ class _VitBlock(nn.Module):
             else:
                 h1 = _layernorm(self.norm1, x)
                 qkv = _linear_h2(at.qkv, h1, b1) if _linear_h2_ok(at.qkv, h1, b1) else _linear_s3(at.qkv, h1)
-            a = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
+            bqk = _linear_out_bound(self.norm1, at.qkv, slice(0, 2 * c))
+            bv = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
+            att = None
+            if terms and _cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4:
+                # the attention kernel hands its output to the projection as terms rows too (|out| <= ba)
+                att, sa = (torch.empty if c % 32 == 0 else torch.zeros)((b * n, (c + 31) // 32 * 64), dtype=torch.float16, device=x.device), _terms_scale(ba)
+                with torch.cuda.device(x.device):
+                    _lib.check(_lib.load().mirx_attention_qkv_f32_split2h_terms(_ptr(qkv), b, n, at.num_heads, 64, 0.125, bqk, bv, sa,
+                                                                                _ptr(att), _stream(x.device)),
+                               "mirx_attention_qkv_f32_split2h_terms")
+            a = torch.empty((b, n, c), dtype=torch.float32, device=x.device) if att is None else None
             with torch.cuda.device(x.device):
                 lib = _lib.load()
-                bqk = _linear_out_bound(self.norm1, at.qkv, slice(0, 2 * c))
-                bv = _linear_out_bound(self.norm1, at.qkv, slice(2 * c, 3 * c))
-                if _cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+                if att is not None:
+                    pass
+                elif _cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
                     # q, k, v are outputs of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
                     _lib.check(lib.mirx_attention_qkv_f32_split2h(_ptr(qkv), b, n, at.num_heads, 64, 0.125, bqk, bv, _ptr(a),
                                                                   _stream(x.device)), "mirx_attention_qkv_f32_split2h")
@@ -1442,7 +1452,8 @@ class _VitBlock(nn.Module):
                     _lib.check(att(_ptr(qkv), b, n, at.num_heads, 64, 0.125, _ptr(a), _stream(x.device)),
                                "mirx_attention_qkv_f32")
             if terms:
-                att, sa = _rows_to_terms(a, ba)
+                if att is None:
+                    att, sa = _rows_to_terms(a, ba)
                 x = _linear_terms(at.proj, att, sa, (b, n), res=x, gamma=self.ls1.gamma)
                 h2t, s2 = _layernorm_terms(self.norm2, x, b2)
                 hidt, sh = _linear_terms(self.mlp.fc1, h2t, s2, (b, n), act=1, terms_bound=bh)

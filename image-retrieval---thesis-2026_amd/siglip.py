@@ -137,13 +137,23 @@ class _EncoderLayer(nn.Module):
         else:
             h1 = _m._layernorm(self.layer_norm1, x)
             qkv = _m._linear_h2(pk, h1, b1) if _m._linear_h2_ok(pk, h1, b1) else _m._linear_s3(pk, h1)      # [b, n, 3c]
-        ctx = torch.empty((b, n, c), dtype=torch.float32, device=x.device)
+        bqk = max(_m._linear_out_bound(self.layer_norm1, sa.q_proj), _m._linear_out_bound(self.layer_norm1, sa.k_proj))
+        bv = _m._linear_out_bound(self.layer_norm1, sa.v_proj)
+        flash = key_mask is None and n >= 32 and sa.head_dim in (32, 64, 72, 96) and b <= 65535
+        ct = None
+        if terms and flash and _m._cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4:
+            # the attention kernel hands its output to the projection as terms rows too (|ctx| <= bctx)
+            ct, sc = (torch.empty if c % 32 == 0 else torch.zeros)((b * n, (c + 31) // 32 * 64), dtype=torch.float16, device=x.device), _m._terms_scale(bctx)
+            with torch.cuda.device(x.device):
+                _lib.check(lib.mirx_attention_qkv_f32_split2h_terms(_m._ptr(qkv), b, n, sa.num_heads, sa.head_dim, float(sa.scale),
+                                                                    bqk, bv, sc, _m._ptr(ct), _m._stream(x.device)),
+                           "mirx_attention_qkv_f32_split2h_terms")
+        ctx = torch.empty((b, n, c), dtype=torch.float32, device=x.device) if ct is None else None
         with torch.cuda.device(x.device):
             st = _m._stream(x.device)
-            bqk = max(_m._linear_out_bound(self.layer_norm1, sa.q_proj), _m._linear_out_bound(self.layer_norm1, sa.k_proj))
-            bv = _m._linear_out_bound(self.layer_norm1, sa.v_proj)
-            flash = key_mask is None and n >= 32 and sa.head_dim in (32, 64, 72, 96) and b <= 65535
-            if flash and _m._cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
+            if ct is not None:
+                pass
+            elif flash and _m._cfg(self).attention_two_fp16 and 0.0 < bqk < 3.0e4 and 0.0 < bv < 3.0e4:
                 # q, k, v come out of a LayerNorm-fed Linear: provable bounds -> two fp16 terms per operand
                 _lib.check(lib.mirx_attention_qkv_f32_split2h(_m._ptr(qkv), b, n, sa.num_heads, sa.head_dim, float(sa.scale),
                                                               bqk, bv, _m._ptr(ctx), st), "mirx_attention_qkv_f32_split2h")
@@ -159,7 +169,8 @@ class _EncoderLayer(nn.Module):
                                                     n, n, float(sa.scale), _m._ptr(ctx), st), "mirx_attention_small")
         # the context is a softmax-weighted average of V rows: bounded like the V rows of the packed projection; |gelu(v)| <= |v|
         if terms:
-            ct, sc = _m._rows_to_terms(ctx, bctx)
+            if ct is None:
+                ct, sc = _m._rows_to_terms(ctx, bctx)
             x = _m._linear_terms(sa.out_proj, ct, sc, (b, n), res=x)
             h2t, s2 = _m._layernorm_terms(self.layer_norm2, x, b2)
             hidt, sh = _m._linear_terms(mlp.fc1, h2t, s2, (b, n), act=2, terms_bound=bh)

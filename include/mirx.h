@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 301
+#define MIRX_VERSION 302
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -463,6 +463,11 @@ int mirx_attention_qkv_f32_split3(const float *qkv, int64_t batch, int n_tokens,
  */
 int mirx_attention_qkv_f32_split2h(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim,
                                    float scale, float qk_bound, float v_bound, float *out, void *stream);
+/* The same attention with the result written as terms rows of out_scale * out (include above: mirx_linear_terms), |out| <=
+ * v_bound (a softmax-weighted average of V rows), so that the output projection reads it without a conversion pass.
+ * out_terms: batch * n_tokens rows of ceil32(heads * head_dim) * 4 bytes. */
+int mirx_attention_qkv_f32_split2h_terms(const float *qkv, int64_t batch, int n_tokens, int heads, int head_dim, float scale,
+                                         float qk_bound, float v_bound, float out_scale, void *out_terms, void *stream);
 
 /*
  * Metric tail over ranked lists, on the device: one pass per query over its

@@ -3,6 +3,7 @@ restatement of softmax(q k^T / sqrt(d)) v -- the attention of timm's vit_base_pa
 (reference model.py:459-463).  Tolerance 3e-6 relative to the largest output (fp32 products and sums,
 v_exp_f32; measured 2-3e-7 on unit-variance inputs)."""
 import ctypes
+import math
 
 import pytest
 import torch
@@ -129,3 +130,31 @@ def test_attention_split2h_matches_float64(b, n, heads, amp, dh):
     ref = _ref(qkv)
     assert torch.isfinite(out).all()
     assert float((out.double() - ref).abs().max()) < 3e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("b,n,heads,dh", [(2, 1370, 12, 64), (1, 1024, 16, 72), (3, 100, 6, 32), (2, 257, 12, 64)])
+def test_attention_split2h_terms_output_carries_the_fp32_output(b, n, heads, dh):
+    """mirx_attention_qkv_f32_split2h_terms: the same attention with the result written as terms rows (the input format of
+    mirx_linear_terms).  hi + lo of every element reproduces the fp32 output of mirx_attention_qkv_f32_split2h to 2^-21 of
+    the bound (two fp16 terms), padding features are zero."""
+    from mirx import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7 * n + heads)
+    qkv = torch.randn((b, n, 3, heads, dh), generator=g, device=dev) * 1.5
+    c = heads * dh
+    cp = (c + 31) // 32 * 32
+    out = torch.empty((b, n, c), device=dev)
+    bqk, bv = float(qkv[:, :, :2].abs().max()), float(qkv[:, :, 2].abs().max())
+    _lib.check(lib.mirx_attention_qkv_f32_split2h(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, dh, dh ** -0.5, bqk, bv,
+                                                  ctypes.c_void_p(out.data_ptr()), None), "mirx_attention_qkv_f32_split2h")
+    scale = 2.0 ** math.floor(math.log2(32768.0 / bv))
+    t = torch.full((b * n, 2 * cp), float("nan"), dtype=torch.float16, device=dev)
+    _lib.check(lib.mirx_attention_qkv_f32_split2h_terms(ctypes.c_void_p(qkv.data_ptr()), b, n, heads, dh, dh ** -0.5, bqk, bv, scale,
+                                                        ctypes.c_void_p(t.data_ptr()), None), "mirx_attention_qkv_f32_split2h_terms")
+    torch.cuda.synchronize()
+    tt = t.view(b * n, cp // 32, 2, 32).double()
+    back = (tt[:, :, 0] + tt[:, :, 1]).reshape(b * n, cp) / scale
+    if cp > c:
+        assert torch.isnan(back[:, c:]).all()        # the launch writes features [0, c): padding belongs to the buffer's owner
+    assert float((back[:, :c] - out.view(b * n, c).double()).abs().max()) <= bv * 2.0 ** -21
