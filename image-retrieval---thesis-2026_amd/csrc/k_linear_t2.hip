@@ -378,36 +378,39 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
 #endif
 }
 
-// Split tiles: sum the `parts` pieces of tile `plain_tiles + blockIdx.x / 16` (piece order) and finish them.  One workgroup =
-// 16 token rows x 256 outputs; thread -> 4 consecutive outputs, 4 rows.
+// Split tiles: sum the `parts` pieces of tile `plain_tiles + blockIdx.x / 64` (piece order) and finish them.  One workgroup =
+// 4 token rows x 256 outputs, one 16-byte vector per thread; the pieces are fetched eight at a time and added in order.
 template <int ACT, bool RES, bool TOUT>
 __global__ __launch_bounds__(256) void k_linear_t2_fix(const float *__restrict__ ws, int parts, int64_t plain_tiles, int ntn,
                                                        int64_t m, const float *__restrict__ bias, int n, const float *res,
                                                        const float *__restrict__ gamma, float out_scale, float *y, char *yt,
                                                        float y_scale, int np) {
-    const int64_t st = blockIdx.x >> 4;
+    const int64_t st = blockIdx.x >> 6;
     const int64_t tile = plain_tiles + st;
     const int n0 = (int)(tile % ntn) * TN;
     const int64_t m0 = (tile / ntn) * TM;
     const int col = n0 + 4 * (threadIdx.x & 63);
-    if (col >= (TOUT ? np : n)) return;
+    const int rl = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6);
+    const int64_t row = m0 + rl;
+    if (col >= (TOUT ? np : n) || row >= m) return;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
     if (bias && col < n) bv = *reinterpret_cast<const f32x4 *>(bias + col);
     if (RES && gamma) gv = *reinterpret_cast<const f32x4 *>(gamma + col);
+    const float *src = ws + st * parts * (int64_t)(TM * TN) + rl * TN + 4 * (threadIdx.x & 63);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < parts; p0 += 8) {
+        f32x4 a[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rl = (blockIdx.x & 15) * 16 + (threadIdx.x >> 6) + 4 * j;
-        const int64_t row = m0 + rl;
-        if (row >= m) continue;
-        const float *src = ws + st * parts * (int64_t)(TM * TN) + rl * TN + 4 * (threadIdx.x & 63);
-        f32x4 v = *reinterpret_cast<const f32x4 *>(src);
-        for (int p = 1; p < parts; ++p) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(src + p * (int64_t)(TM * TN));
+        for (int j = 0; j < 8; ++j)
+            a[j] = p0 + j < parts ? *reinterpret_cast<const f32x4 *>(src + (p0 + j) * (int64_t)(TM * TN)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += a[e];
-        }
-        finish4<ACT, RES, TOUT>(v, row, col, bv, gv, out_scale, n, res, y, yt, y_scale, np);
+        for (int j = 0; j < 8; ++j)
+            if (p0 + j < parts) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (p0 + j) ? v[e] + a[j][e] : a[j][e];
+            }
     }
+    finish4<ACT, RES, TOUT>(v, row, col, bv, gv, out_scale, n, res, y, yt, y_scale, np);
 }
 
 // fp32 rows [m][k] (row stride ldx floats) -> terms rows [m][kp / 32] lines, scaled by the power of two `scale`.
@@ -524,7 +527,7 @@ hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, co
                            reinterpret_cast<const char *>(wt), bias, n, res, gamma, out_scale, y,                      \
                            reinterpret_cast<char *>(yt), y_scale, np, ntn, plain, per_xcd, parts, ws);                 \
         if (split > 0)                                                                                                 \
-            hipLaunchKernelGGL((k_linear_t2_fix<A, R, T>), dim3((unsigned)(split * 16)), dim3(256), 0, st, ws, parts, plain, ntn, \
+            hipLaunchKernelGGL((k_linear_t2_fix<A, R, T>), dim3((unsigned)(split * 64)), dim3(256), 0, st, ws, parts, plain, ntn, \
                                m, bias, n, res, gamma, out_scale, y, reinterpret_cast<char *>(yt), y_scale, np);       \
     }
     if (yt) {
