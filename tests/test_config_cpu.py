@@ -58,3 +58,31 @@ def test_algorithmic_work_formulas_have_the_known_answers():
     flop, nbytes = bench.vit_work(t, c, 4 * c, 12, 588)
     assert abs(flop - (2.0 * t * 588 * c + 12 * (24.0 * t * c * c + 4.0 * t * t * c))) < 1e6
     assert abs(nbytes - 4.0 * (t * (588 + c) + 12 * 20 * t * c)) < 1e3
+
+
+def test_terms_rows_layout_and_the_tail_split_plan():
+    """Host side of the token-major Linear on pre-split operands (include/mirx.h, mirx_linear_terms): the terms-rows layout of
+    the weights (per 32 features one 128-byte line: fp16 high terms | fp16 low terms, zero padding) reproduces the scaled
+    matrix to two fp16 terms; the launcher's plan (no GPU needed: it counts tiles) cuts only the last, partly filled round."""
+    import mirx.model as mm
+    from mirx import _lib
+    torch.manual_seed(3)
+    w = torch.randn(70, 200) * 3.0
+    t = mm._terms_of(w, 8.0)                                            # [rows, ceil32(k) / 32, 2, 32] fp16
+    assert t.shape == (70, 7, 2, 32) and t.dtype == torch.float16
+    back = (t[:, :, 0].double() + t[:, :, 1].double()).reshape(70, 224) / 8.0
+    assert float((back[:, :200] - w.double()).abs().max()) <= float(w.abs().max()) * 2.0 ** -21
+    assert float(back[:, 200:].abs().max()) == 0.0
+    lin = torch.nn.Linear(200, 70)
+    wt, ws = mm._linear_terms_weights(lin)
+    assert wt.shape == (256, 7, 2, 32) and float(wt[70:].abs().max()) == 0.0        # rows padded to the 256-output tile
+    assert 2.0 ** 13 <= float(lin.weight.abs().max()) * ws < 2.0 ** 14
+    assert mm._terms_scale(6.0) == 4096.0 and mm._terms_scale(32768.0) == 1.0
+    lib = _lib.load()
+    tile = 256 * 256 * 4
+    assert lib.mirx_linear_terms_workspace_bytes(256 * 16, 768, 256 * 16) == 0                  # 256 tiles: whole rounds only
+    assert lib.mirx_linear_terms_workspace_bytes(5120, 768, 3328) == 4 * 24 * tile             # 260 tiles: 4 cut into 24 pieces
+    assert lib.mirx_linear_terms_workspace_bytes(300, 96, 200) == 2 * 3 * tile                 # 2 tiles, 3 stages: cut into 3
+    assert lib.mirx_linear_terms_workspace_bytes(43840, 768, 768) == 4 * 24 * tile             # DINOv2 proj at 32 images: 516 tiles
+    assert lib.mirx_linear_terms_workspace_bytes(256 * 200, 768, 256) == 0                     # 200 tiles: the round is 78 % full
+    assert lib.mirx_linear_terms_workspace_bytes(0, 768, 768) == 0
