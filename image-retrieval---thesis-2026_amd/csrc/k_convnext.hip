@@ -8,6 +8,8 @@
 // collide on a bank); a thread owns one channel and two (three) output rows, keeps that channel's 49
 // weights in registers, and for every kernel row reads 22 inputs for 7 x 16 FMAs.  The NHWC store
 // puts the 32 channels of a pixel in one 128-byte segment.
+#include <cstdio>
+
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -33,41 +35,73 @@ __global__ __launch_bounds__(32 * (DT / RPT), 2) void k_dwconv7(const float *__r
     const int64_t img = blockIdx.z;
     const int y0 = ty * DT, x0 = tx * DT;
     const float *xi = x + (img * c + c0) * (int64_t)h * wd;
-    // The global loads of a thread are issued in batches of 16 before the matching LDS stores (addresses clamped,
-    // values zeroed when they are stored): with a load -> store loop the workgroup paid one HBM latency per element
-    // (61 per thread); one batch of 61 costs more registers than two workgroups per CU can have.
-    constexpr int N_IN = (DCH * DP * DP + NTH - 1) / NTH;       // 61 per thread (16 / 2), 81 (12 / 3)
-    constexpr int NB = 16;
+    // Staging.  A wavefront step covers RW whole patch rows (lane -> row lane / DP, column lane % DP: one division per
+    // thread, outside the loop), the workgroup RSTEP rows; a thread's (channel, patch row) advances by RSTEP rows per step
+    // with at most one wrap.  (The first version numbered the patch elements linearly and took channel / row / column of
+    // every element by division: ~35 VALU per loaded value -- in-kernel stamps showed the staging phase at 40 k cycles
+    // against 20 k for the 49-tap arithmetic, VALU-bound on index math.)  Loads go in batches of NB before the matching LDS
+    // stores (addresses clamped, values zeroed when stored) so that a batch costs one memory round trip.
+    constexpr int RW = 64 / DP, RSTEP = RW * (NTH / 64);
+    constexpr int NSTEP = (DCH * DP + RSTEP - 1) / RSTEP;        // 88 steps (16 / 2), 96 (12 / 3)
+#ifndef MIRX_DW_NB
+#define MIRX_DW_NB 16
+#endif
+    constexpr int NB = MIRX_DW_NB;
+#ifdef MIRX_DW_STAMPS
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int rsub = lane / DP, q = lane - rsub * DP;
+        const bool lane_on = rsub < RW;
+        const int row0 = wave * RW + (lane_on ? rsub : 0);
+        int chp = row0 / DP, r = row0 - chp * DP;                // this thread's patch row: channel chp, row r
+        const int xx = x0 + q - 3;
+        const bool x_in = xx >= 0 && xx < wd;
+        const int xc = xx < 0 ? 0 : (xx >= wd ? wd - 1 : xx);
+        const int ch_max = (c - c0 < DCH ? c - c0 : DCH) - 1;    // last valid channel of this workgroup
 #pragma unroll 1
-    for (int t0 = 0; t0 < N_IN; t0 += NB) {
-        float vin[NB];
+        for (int t0 = 0; t0 < NSTEP; t0 += NB) {
+            float vin[NB];
+            int chs = chp, rs = r;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            int i = threadIdx.x + NTH * (t0 + t);
-            if (i >= DCH * DP * DP) i = DCH * DP * DP - 1;
-            int ch = i / (DP * DP);
-            const int r = (i / DP) % DP, q = i % DP;
-            int yy = y0 + r - 3, xx = x0 + q - 3;
-            yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
-            xx = xx < 0 ? 0 : (xx >= wd ? wd - 1 : xx);
-            if (c0 + ch >= c) ch = c - 1 - c0;
-            vin[t] = xi[((int64_t)ch * h + yy) * wd + xx];
-        }
+            for (int t = 0; t < NB; ++t) {
+                const int chc = chp > ch_max ? ch_max : chp;
+                int yy = y0 + r - 3;
+                yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+                vin[t] = xi[(chc * h + yy) * wd + xc];
+                r += RSTEP;
+                if (r >= DP) {
+                    r -= DP;
+                    ++chp;
+                }
+            }
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int i = threadIdx.x + NTH * (t0 + t);
-            const int ch = i / (DP * DP), r = (i / DP) % DP, q = i % DP;
-            const int yy = y0 + r - 3, xx = x0 + q - 3;
-            const bool in = c0 + ch < c && yy >= 0 && yy < h && xx >= 0 && xx < wd;
-            if (i < DCH * DP * DP) sm[ch * DPITCH + r * DP + q] = in ? vin[t] : 0.0f;
+            for (int t = 0; t < NB; ++t) {
+                const int yy = y0 + rs - 3;
+                const bool in = chs <= ch_max && yy >= 0 && yy < h && x_in;
+                if (lane_on && chs < DCH && t0 + t < NSTEP) sm[chs * DPITCH + rs * DP + q] = in ? vin[t] : 0.0f;
+                rs += RSTEP;
+                if (rs >= DP) {
+                    rs -= DP;
+                    ++chs;
+                }
+            }
         }
     }
     __syncthreads();
+#ifdef MIRX_DW_STAMPS
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+#endif
     const int ch = threadIdx.x & 31, rg = threadIdx.x >> 5;        // channel, group of RPT output rows
     if (c0 + ch >= c) return;
     float wk[49];
 #pragma unroll
     for (int i = 0; i < 49; ++i) wk[i] = w[(int64_t)(c0 + ch) * 49 + i];
+#ifdef MIRX_DW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+#endif
     const float b = bias ? bias[c0 + ch] : 0.0f;
     const float *pch = sm + ch * DPITCH;
     float *yo = y + img * (int64_t)h * wd * c + c0 + ch;
@@ -92,6 +126,12 @@ __global__ __launch_bounds__(32 * (DT / RPT), 2) void k_dwconv7(const float *__r
         for (int q = 0; q < DT; ++q)
             if (x0 + q < wd) yo[((int64_t)(y0 + r) * wd + x0 + q) * c] = acc[q];
     }
+#ifdef MIRX_DW_STAMPS
+    const unsigned long long t3_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 3 && (blockIdx.z & 15) == 5)
+        printf("dwconv<%d,%d> img %d: staging %llu, weights %llu, compute+store %llu cycles\n", DT, RPT, (int)blockIdx.z, t1_ - t0_,
+               t2_ - t1_, t3_ - t2_);
+#endif
 }
 
 // Global response normalisation (timm GlobalResponseNorm, channels last), split in two HBM passes instead of
