@@ -32,6 +32,20 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
+// Diagnostic build -DMIRX_C1H2_STAMPS: s_memtime at the phase boundaries of every stage, wave 0 of each workgroup, into
+// g_c1_stamps (read back by tools/bench_conv1x1.py --stamps through mirx_debug_c1_stamps); never in the shipped library.
+#ifdef MIRX_C1H2_STAMPS
+__device__ unsigned long long g_c1_stamps[8192 * 8];
+#define C1_STAMP(ACC)                                                 \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        ACC += now_ - st_t;                                           \
+        st_t = now_;                                                  \
+    }
+#else
+#define C1_STAMP(ACC)
+#endif
+
 constexpr int CM = 128;            // output channels per workgroup
 constexpr int CP = 128;            // pixels per workgroup
 constexpr int KC = 16;             // channels per stage
@@ -184,6 +198,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+#ifdef MIRX_C1H2_STAMPS
+    unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_store = 0;
+    const unsigned long long st_begin = st_t, rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
     auto stage = [&](int kt, int cur, float (&rnext)[NPT][NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NPT][NR],
                      const float (&scs)[8], const float (&shs)[8]) {
@@ -193,11 +211,15 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         // were warm: the LDS-DMA pieces were still landing when the count had already dropped to 8), i.e. LDS-DMA and
         // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
         // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
+        C1_STAMP(st_store)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C1_STAMP(st_wait)
         __syncthreads();
+        C1_STAMP(st_bar)
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
+        C1_STAMP(st_issue)
         const char *sb = sm + cur * STAGE_N;
         f16x8 a[2][2], b[NN][2];
 #pragma unroll
@@ -222,6 +244,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], c, 0, 0, 0);
                 acc[mi][ni] = c;
             }
+        C1_STAMP(st_mfma)
         store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
     };
     dma_w(0, 0);
@@ -272,6 +295,20 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         stage(kt + 1, 1, rb, scb, shb, ra, sca, sha);
     }
     if (kt < nk) stage(kt, 0, ra, sca, sha, rb, scb, shb);
+#ifdef MIRX_C1H2_STAMPS
+    if (threadIdx.x == 0) {
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = g_c1_stamps + ((blockIdx.x + blockIdx.y * gridDim.x) & 8191) * 8;
+        o[0] = now_ - st_begin;
+        o[1] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        o[2] = nk;
+        o[3] = st_wait;
+        o[4] = st_bar;
+        o[5] = st_issue;
+        o[6] = st_mfma;
+        o[7] = st_store;
+    }
+#endif
 
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 128 (ni >> 1) + 64 wn + 32 (ni & 1) + (lane & 31)
@@ -351,6 +388,12 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 }
 
 }  // namespace
+
+#ifdef MIRX_C1H2_STAMPS
+extern "C" int mirx_debug_c1_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c1_stamps), sizeof(g_c1_stamps));
+}
+#endif
 
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,

@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--stamps", action="store_true", help="diagnostic library (-DMIRX_C1H2_STAMPS): cycle stamps of the last h2 launch per block")
     ap.add_argument("--hw", type=int, nargs="*", default=None, help="experiment: block-3 layer set (256..992 channels) at these pixel counts per image")
     a = ap.parse_args()
     lib = _lib.load()
@@ -68,6 +69,18 @@ def main():
             tot[kind] += ms
             gb = sum((l[0] + 128) * 4 * hw * a.batch for l in layers) / 1e9
             print(f"side {side:2d} ({nl:2d} layers) {kind}: {ms:7.3f} ms   {gb / ms:6.2f} TB/s algorithmic", flush=True)
+            if kind == "h2" and a.stamps:
+                import numpy as np
+                dbg = ctypes.CDLL(_lib.LIB_PATH)
+                sb = np.zeros(8192 * 8, dtype=np.uint64)
+                assert dbg.mirx_debug_c1_stamps(sb.ctypes.data_as(ctypes.c_void_p)) == 0
+                t = sb.reshape(8192, 8).astype(np.float64)
+                t = t[t[:, 2] > 0]
+                nk_ = t[:, 2]
+                md = lambda v: float(np.median(v))      # noqa: E731
+                print(f"   stamps (last layer, cin {layers[-1][0]}, {len(t)} wgs): K loop {md(t[:, 0] / nk_):.0f} cycles/stage = wait {md(t[:, 3] / nk_):.0f} "
+                      f"+ barrier {md(t[:, 4] / nk_):.0f} + issue {md(t[:, 5] / nk_):.0f} + frags/mfma {md(t[:, 6] / nk_):.0f} + split/store {md(t[:, 7] / nk_):.0f}; "
+                      f"clock {md(t[:, 0] / t[:, 1] * 100):.0f} MHz", flush=True)
         del buf, y
     print(f"total s3 {tot['s3']:.2f} ms, h2 {tot['h2']:.2f} ms per {a.batch} images")
 
