@@ -86,3 +86,22 @@ def test_terms_rows_layout_and_the_tail_split_plan():
     assert lib.mirx_linear_terms_workspace_bytes(43840, 768, 768) == 4 * 24 * tile             # DINOv2 proj at 32 images: 516 tiles
     assert lib.mirx_linear_terms_workspace_bytes(256 * 200, 768, 256) == 0                     # 200 tiles: the round is 78 % full
     assert lib.mirx_linear_terms_workspace_bytes(0, 768, 768) == 0
+
+
+def test_default_transform_is_the_float32_arithmetic_of_totensor_and_normalize():
+    """retriever.default_transform computes (u / 255 - mean) / std in numpy float32 (torch's CPU operators cost 10+ ms per
+    call on the GPU boxes); the result must be the bits the torch expression of ToTensor + Normalize gives."""
+    import numpy as np
+    from PIL import Image
+    from mirx.retriever import IMAGENET_MEAN, IMAGENET_STD, default_transform
+    img = Image.fromarray(np.random.default_rng(1).integers(0, 256, (300, 280, 3), dtype=np.uint8))
+    got = default_transform(224)(img)
+    w, h = img.size
+    nw, nh = (256, int(256 * h / w)) if w <= h else (int(256 * w / h), 256)
+    ref = img.convert("RGB").resize((nw, nh), Image.BILINEAR)
+    left, top = int(round((nw - 224) / 2.0)), int(round((nh - 224) / 2.0))
+    ref = ref.crop((left, top, left + 224, top + 224))
+    x = torch.from_numpy(np.asarray(ref, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    want = (x - torch.tensor(IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    assert got.dtype == torch.float32 and got.shape == (3, 224, 224) and got.is_contiguous()
+    assert torch.equal(got, want)
