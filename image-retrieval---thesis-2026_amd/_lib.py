@@ -59,6 +59,7 @@ SYMBOLS = {
                                  ctypes.POINTER(ctypes.c_int32), _int, _vp, _vp, _vp, _vp, _vp]),
     "mirx_linear_split2h": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_rows_to_terms": (_int, [_vp, _i64, _int, _i64, ctypes.c_float, _vp, _vp]),
+    "mirx_layernorm_patch2_nhwc": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, ctypes.c_float, _vp, _vp]),
     "mirx_layernorm_terms": (_int, [_vp, _i64, _int, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "mirx_linear_terms": (_int, [_vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_float, _vp, _i64,
                                  _vp]),
@@ -67,6 +68,9 @@ SYMBOLS = {
     "mirx_linear_split3_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "mirx_linear_split2h_nchw": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,
                                         _vp]),
+    "mirx_linear_split2h_gelu_grn": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp]),
+    "mirx_linear_split2h_grn_rows": (_int, [_vp, _i64, _int, _int, _vp, _vp, _int, _vp, _vp, ctypes.c_float, _vp, ctypes.c_float, _vp,
+                                            _vp]),
     "mirx_grn_norm_nhwc": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "mirx_grn_scale": (_int, [_vp, _vp, _i64, _int, ctypes.c_float, _vp, _vp, _vp]),
     "mirx_conv1x1_bn_relu_split3": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
@@ -99,12 +103,13 @@ SYMBOLS = {
     "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "mirx_conv1x1_bn_relu": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_dwconv7x7_nchw_to_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "mirx_dwconv7x7_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool_split3": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
     "mirx_stem_conv7_bn_relu_pool": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp]),
 }
 
 _lib = None
-ABI_VERSION = 302          # include/mirx.h MIRX_VERSION this binding was written against
+ABI_VERSION = 303          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():

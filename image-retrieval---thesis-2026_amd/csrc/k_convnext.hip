@@ -134,6 +134,75 @@ __global__ __launch_bounds__(32 * (DT / RPT), 2) void k_dwconv7(const float *__r
 #endif
 }
 
+// ---- depthwise 7x7 on a channels-last map (NHWC in, NHWC out): no LDS, no staging phase ---------------------------------
+// With channels last, a wavefront's lanes are 64 consecutive channels of one pixel: every load and store is one 256-byte
+// run, and a thread (one channel) can walk a strip of DR output rows along x with a 7-column window of its DR + 6 input
+// rows in registers: a step loads ONE new column (DR + 6 values), multiplies the whole window (DR x 49 FMAs) and stores DR
+// outputs.  The window rotates by renaming (the x loop is unrolled by 7), an input value is fetched (DR + 6) / DR times
+// (from L2 after the first), weights arrive as [49][c] (transposed once on the host side of the model) in 49 registers.
+// grid: (ceil(h / DR) strips, ceil(c / 64), n); block: 64.
+constexpr int DR = 4;
+
+__global__ __launch_bounds__(64) void k_dwconv7_nhwc(const float *__restrict__ x, const float *__restrict__ wt,
+                                                     const float *__restrict__ bias, int c, int h, int wd,
+                                                     float *__restrict__ y) {
+    const int ch = blockIdx.y * 64 + threadIdx.x;
+    if (ch >= c) return;
+    const int y0 = blockIdx.x * DR;
+    const int64_t img = blockIdx.z;
+    const float *xi = x + img * (int64_t)h * wd * c + ch;
+    float *yo = y + img * (int64_t)h * wd * c + ch;
+    float wk[49];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) wk[i] = wt[(int64_t)i * c + ch];
+    const float b = bias ? bias[ch] : 0.0f;
+    // row offsets (in elements) and validity of the DR + 6 input rows of this strip
+    int roff[DR + 6];
+    bool rok[DR + 6];
+#pragma unroll
+    for (int r = 0; r < DR + 6; ++r) {
+        const int yy = y0 + r - 3;
+        rok[r] = yy >= 0 && yy < h;
+        roff[r] = (yy < 0 ? 0 : (yy >= h ? h - 1 : yy)) * wd * c;
+    }
+    // win[k][r]: input column (x_out - 3 + k) of row r, for the output column being computed
+    float win[7][DR + 6];
+    auto load_col = [&](int xx, float (&col)[DR + 6]) {
+        const bool xok = xx >= 0 && xx < wd;
+        const int xc = (xx < 0 ? 0 : (xx >= wd ? wd - 1 : xx)) * c;
+#pragma unroll
+        for (int r = 0; r < DR + 6; ++r) {
+            const float v = xi[roff[r] + xc];
+            col[r] = (xok && rok[r]) ? v : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) load_col(k - 3, win[k]);          // columns -3 .. 2 of output column 0
+    // one output column: the newest window column (input x_out + 3) arrives in slot S, the window's columns in x order are
+    // slots S + 1, .., S + 7 (mod 7)
+#define MIRX_DW_STEP(S)                                                                          \
+    if (xo < wd) {                                                                               \
+        load_col(xo + 3, win[((S) + 6) % 7]);                                                    \
+        float acc[DR];                                                                           \
+        _Pragma("unroll") for (int r = 0; r < DR; ++r) acc[r] = b;                               \
+        _Pragma("unroll") for (int ky = 0; ky < 7; ++ky)                                         \
+            _Pragma("unroll") for (int kx = 0; kx < 7; ++kx)                                     \
+                _Pragma("unroll") for (int r = 0; r < DR; ++r)                                   \
+                    acc[r] = fmaf(win[((S) + kx) % 7][r + ky], wk[ky * 7 + kx], acc[r]);         \
+        _Pragma("unroll") for (int r = 0; r < DR; ++r)                                           \
+            if (y0 + r < h) yo[((int64_t)(y0 + r) * wd + xo) * c] = acc[r];                      \
+        ++xo;                                                                                    \
+    }
+    // at step S the window slots in x order start at slot S: slot (S + k) % 7 holds input column xo - 3 + k; the new column
+    // xo + 3 goes to slot (S + 6) % 7, which held column xo - 4 (no longer needed)
+    int xo = 0;
+#pragma unroll 1
+    while (xo < wd) {
+        MIRX_DW_STEP(0) MIRX_DW_STEP(1) MIRX_DW_STEP(2) MIRX_DW_STEP(3) MIRX_DW_STEP(4) MIRX_DW_STEP(5) MIRX_DW_STEP(6)
+    }
+#undef MIRX_DW_STEP
+}
+
 // Global response normalisation (timm GlobalResponseNorm, channels last), split in two HBM passes instead of
 // PyTorch's eight: (1) gx[b][c] = || x[b, :, :, c] ||_2, (2) x = x * scale[b][c] + shift[c] in place, with
 // scale = 1 + weight * gx / (mean_c gx + eps) computed by the caller on the tiny [n][c] tensor.
@@ -193,6 +262,15 @@ __global__ __launch_bounds__(256) void k_grn_scale(const float *__restrict__ gx,
 }
 
 }  // namespace
+
+hipError_t launch_dwconv7_nhwc(const float *x, const float *wt, const float *bias, int64_t n, int c, int h, int wd, float *y,
+                               hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 65535 || (c + 63) / 64 > 65535 || (int64_t)h * wd * c > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dwconv7_nhwc, dim3((unsigned)((h + DR - 1) / DR), (unsigned)((c + 63) / 64), (unsigned)n), dim3(64), 0, st,
+                       x, wt, bias, c, h, wd, y);
+    return hipGetLastError();
+}
 
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
                           float *y, hipStream_t st) {

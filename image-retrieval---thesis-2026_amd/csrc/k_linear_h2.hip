@@ -47,13 +47,18 @@ constexpr int KC = 16;             // features per stage
 constexpr int PLANE = 128 * KC * 2;            // bytes of one term of one operand stage (4 KiB)
 constexpr int STAGE = 4 * PLANE;               // x terms [0, 2), w terms [2, 4): 16 KiB
 
-template <int ACT, bool RES, bool NCHW, bool GRN>
+// SQ (row-major outputs only): the workgroup also returns the column sums of v^2 over its token rows, split by image (a tile
+// of 128 rows spans at most two images when tokens_per_image >= 128): sq_out[tile_m][0 / 1][n] -- the partial sums of
+// ConvNeXtV2's global response norm ||hid[b, :, c]||_2, so that no separate pass has to read the 4C-wide hidden map again.
+// Fixed summation order (registers by row, the two lane halves, the two wave rows): bit-reproducible.
+template <int ACT, bool RES, bool NCHW, bool GRN, bool SQ = false>
 __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ x, int64_t m, int k,
                                                       const uint16_t *__restrict__ w3,
                                                       const float *__restrict__ bias, int n, const float *res,
                                                       const float *__restrict__ gamma, float *y, int ntn,
                                                       int64_t total_tiles, int64_t per_xcd, int tpi, float x_scale,
-                                                      float out_scale, const float *__restrict__ xb_dev) {
+                                                      float out_scale, const float *__restrict__ xb_dev,
+                                                      float *__restrict__ sq_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     // xb_dev: the input's bound lives (partly) on the device -- |x * gamma| <= x_scale * xb_dev[0] with `x_scale` the host's
     // bound on |x| and xb_dev[0] the largest |gamma| (ConvNeXt GRN scale, computed per forward); the kernel derives the
@@ -241,12 +246,14 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
     }
     // epilogue: register r of tile (mi, ni) = token m0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // output n0 + 64 wn + 32 ni + (lane & 31): a half-wave stores 128 contiguous bytes of one token row
+    float sq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                                  // SQ: [ni][first / second image of the tile]
+    const int64_t second = SQ ? (m0 / tpi + 1) * (int64_t)tpi : 0;              // first row of the tile's second image
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int col = n0 + wn * 64 + 32 * ni + (lane & 31);
         if (col >= n) continue;                                 // zero-padded weight rows of the last output tile
         const float bv = bias ? bias[col] : 0.f;
-        const float gv = (RES && gamma) ? gamma[col] : 1.f;
+        const float gv = (RES && gamma && !GRN) ? gamma[col] : 1.f;       // (GRN: `gamma` is the input scale, not a LayerScale)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -260,15 +267,61 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                     if (RES) v = res[row * n + col] + gv * v;
                 }
                 y[row * n + col] = v;
+                if (SQ) {
+                    if (row < second) sq[ni][0] = fmaf(v, v, sq[ni][0]);
+                    else sq[ni][1] = fmaf(v, v, sq[ni][1]);
+                }
             }
+    }
+    if (SQ) {
+        __syncthreads();                                        // every wave is done with the stage buffers
+        float *ssq = reinterpret_cast<float *>(sm);             // [wave row wm][image 0 / 1][128 columns]
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+                const float tot = sq[ni][im] + __shfl_xor(sq[ni][im], 32, 64);
+                if (lane < 32) ssq[(wm * 2 + im) * TN + wn * 64 + ni * 32 + lane] = tot;
+            }
+        __syncthreads();
+        const int im = threadIdx.x >> 7, cl = threadIdx.x & 127;
+        if (n0 + cl < n) sq_out[((m0 / TM) * 2 + im) * (int64_t)n + n0 + cl] = ssq[im * TN + cl] + ssq[(2 + im) * TN + cl];
     }
 }
 
 }  // namespace
 
+namespace {
+// gx[img][col] = sqrt( sum over the 128-row tiles that touch image img of its partial ): k_linear_h2<.., SQ>'s sq_out summed in tile
+// order (deterministic).  thread -> (image, column).
+__global__ __launch_bounds__(256) void k_grn_norm_partials(const float *__restrict__ part, int tpi, int64_t n_img, int c,
+                                                           float *__restrict__ gx) {
+    const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (it >= n_img * c) return;
+    const int64_t img = it / c;
+    const int col = (int)(it - img * c);
+    const int64_t t0 = img * tpi / TM, t1 = ((img + 1) * tpi - 1) / TM;
+    float acc = 0.f;
+    for (int64_t t = t0; t <= t1; ++t) {
+        const int sel = (t * TM) / tpi == img ? 0 : 1;
+        acc += part[(t * 2 + sel) * (int64_t)c + col];
+    }
+    gx[it] = sqrtf(acc);
+}
+}  // namespace
+
+hipError_t launch_grn_norm_partials(const float *part, int tpi, int64_t n_img, int c, float *gx, hipStream_t st) {
+    if (n_img <= 0) return hipSuccess;
+    if (tpi < TM || c < 1) return hipErrorInvalidValue;
+    const int64_t blocks = (n_img * c + 255) / 256;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_grn_norm_partials, dim3((unsigned)blocks), dim3(256), 0, st, part, tpi, n_img, c, gx);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
                             const float *res, const float *gamma, float x_scale, float out_scale, float *y,
-                            int tokens_per_image, const float *xb_dev, hipStream_t st) {
+                            int tokens_per_image, const float *xb_dev, hipStream_t st, bool rows_out, float *sq_out) {
     if (m <= 0) return hipSuccess;
     if (k % KC || n < 1 || act < 0 || act > 2) return hipErrorInvalidValue;
     const int ntn = (n + TN - 1) / TN;                 // w2 holds ntn * 128 rows, zero beyond n
@@ -285,7 +338,17 @@ hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2
         hipLaunchKernelGGL((k_linear_h2<A, R, C, G>), grid, dim3(256), lds, st, x, m, k, w2, bias, n, res, gamma, y, ntn, \
                            total, per_xcd, tokens_per_image, x_scale, out_scale, xb_dev);                  \
     }
-    if (tokens_per_image > 0) {                       // ConvNeXt block tail / downsample: `gamma` = GRN input scale [images][k] or null
+    if (sq_out) {                                     // ConvNeXt fc1 + GELU with the GRN partial sums (row-major)
+        if (act != 1 || res || gamma || xb_dev || tokens_per_image < TM) return hipErrorInvalidValue;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_h2<1, false, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_linear_h2<1, false, false, false, true>), grid, dim3(256), lds, st, x, m, k, w2, bias, n, res, gamma, y,
+                           ntn, total, per_xcd, tokens_per_image, x_scale, out_scale, xb_dev, sq_out);
+    } else if (tokens_per_image > 0 && rows_out) {    // ConvNeXt block tail on a channels-last stream: GRN input scale, row-major output
+        if (act || !gamma) return hipErrorInvalidValue;
+        if (res) MIRX_H2(0, true, false, true) else MIRX_H2(0, false, false, true)
+    } else if (tokens_per_image > 0) {                // ConvNeXt block tail / downsample: `gamma` = GRN input scale [images][k] or null
         if (act) return hipErrorInvalidValue;
         if (gamma) {
             if (res) MIRX_H2(0, true, true, true) else MIRX_H2(0, false, true, true)

@@ -40,7 +40,7 @@ template <bool TERMS, int RV>
 __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict__ x, int64_t m, int c,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float eps, float *__restrict__ y, char *__restrict__ yt, float scale,
-                                                        int cp) {
+                                                        int cp, int patch_w, int patch_h) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -64,7 +64,15 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict_
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
-    f32x4 *yr = reinterpret_cast<f32x4 *>(y + row * c);
+    // patch_w > 0: the rows are the pixels of channels-last maps [image][patch_h][patch_w][c] and the result goes to the
+    // 2 x 2 patch rows of a stride-2 convolution, [image][patch_h / 2][patch_w / 2][(ky, kx, c)] (ConvNeXt downsample)
+    int64_t orow = row * c;
+    if (!TERMS && patch_w > 0) {
+        const int64_t hw = (int64_t)patch_w * patch_h, im = row / hw;
+        const int rem = (int)(row - im * hw), py = rem / patch_w, px = rem - py * patch_w;
+        orow = (((im * (patch_h >> 1) + (py >> 1)) * (patch_w >> 1) + (px >> 1)) * 4 + ((py & 1) * 2 + (px & 1))) * c;
+    }
+    f32x4 *yr = reinterpret_cast<f32x4 *>(y + orow);
     char *tr = yt + row * ((int64_t)cp * 4);
 #pragma unroll
     for (int j = 0; j < RV; ++j) {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void k_attention_small(const float *__restrict
 }  // namespace
 
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
-                                 float *y, int tokens_per_image, hipStream_t st, void *yt, float scale) {
+                                 float *y, int tokens_per_image, hipStream_t st, void *yt, float scale, int patch_w, int patch_h) {
     if (m <= 0) return hipSuccess;
     if (c < 4 || c % 4) return hipErrorInvalidValue;
     if (yt) {
@@ -255,7 +263,7 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
         const int cp = (c + 31) / 32 * 32;
         if (cp > 8192) return hipErrorInvalidValue;
 #define MIRX_LNT(RV) hipLaunchKernelGGL((k_layernorm_rows<true, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
-                                        nullptr, reinterpret_cast<char *>(yt), scale, cp)
+                                        nullptr, reinterpret_cast<char *>(yt), scale, cp, 0, 0)
         if (cp <= 512) MIRX_LNT(2); else if (cp <= 1024) MIRX_LNT(4); else if (cp <= 2048) MIRX_LNT(8); else if (cp <= 4096) MIRX_LNT(16); else MIRX_LNT(32);
 #undef MIRX_LNT
         return hipGetLastError();
@@ -273,7 +281,7 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
         if (blocks > 0x7fffffff) return hipErrorInvalidValue;
         if (c > 8192) return hipErrorInvalidValue;
 #define MIRX_LN(RV) hipLaunchKernelGGL((k_layernorm_rows<false, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
-                                       y, nullptr, 1.f, 0)
+                                       y, nullptr, 1.f, 0, patch_w, patch_h)
         if (c <= 512) MIRX_LN(2); else if (c <= 1024) MIRX_LN(4); else if (c <= 2048) MIRX_LN(8); else if (c <= 4096) MIRX_LN(16); else MIRX_LN(32);
 #undef MIRX_LN
     }

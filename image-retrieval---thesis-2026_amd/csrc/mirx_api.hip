@@ -820,6 +820,34 @@ int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const 
     return MIRX_OK;
 }
 
+int mirx_linear_split2h_gelu_grn(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                                 const float *bias_or_null, int n, float x_scale, float out_scale, float *y, float *partials,
+                                 float *gx, void *stream) {
+    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 128 && k >= 16 && k % 16 == 0 && n >= 1,
+               "linear_split2h_gelu_grn: k must be a multiple of 16, tokens_per_image at least 128");
+    MIRX_CHECK(n_img == 0 || (x && w2 && y && partials && gx), "linear_split2h_gelu_grn: null buffer");
+    MIRX_CHECK(x_scale > 0.f && out_scale > 0.f, "linear_split2h_gelu_grn: scales must be positive");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MIRX_HIP(launch_linear_h2(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, 1, nullptr,
+                              nullptr, x_scale, out_scale, y, tokens_per_image, nullptr, st, false, partials));
+    MIRX_HIP(launch_grn_norm_partials(partials, tokens_per_image, n_img, n, gx, st));
+    return MIRX_OK;
+}
+
+int mirx_linear_split2h_grn_rows(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                                 const float *bias_or_null, int n, const float *residual_or_null, const float *input_scale,
+                                 float x_bound, const float *input_scale_max, float w_inv, float *y, void *stream) {
+    MIRX_CHECK(n_img >= 0 && tokens_per_image >= 1 && k >= 16 && k % 16 == 0 && n >= 1,
+               "linear_split2h_grn_rows: k must be a multiple of 16");
+    MIRX_CHECK(n_img == 0 || (x && w2 && y && input_scale && input_scale_max), "linear_split2h_grn_rows: null buffer");
+    MIRX_CHECK(x != y, "linear_split2h_grn_rows: y may alias the residual, not the input");
+    MIRX_CHECK(x_bound > 0.f && w_inv > 0.f, "linear_split2h_grn_rows: x_bound and w_inv must be positive");
+    MIRX_HIP(launch_linear_h2(x, n_img * tokens_per_image, k, reinterpret_cast<const uint16_t *>(w2), bias_or_null, n, 0,
+                              residual_or_null, input_scale, x_bound, w_inv, y, tokens_per_image, input_scale_max,
+                              reinterpret_cast<hipStream_t>(stream), true));
+    return MIRX_OK;
+}
+
 int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
                              const float *bias_or_null, int n, const float *residual_or_null,
                              const float *input_scale_or_null, float x_bound, const float *input_scale_max_or_null,
@@ -885,6 +913,17 @@ int mirx_layernorm(const float *x, int64_t m, int c, const float *gamma_or_null,
     MIRX_CHECK(eps >= 0.f, "layernorm: eps must be non-negative");
     MIRX_HIP(launch_layernorm_rows(x, m, c, gamma_or_null, beta_or_null, eps, y, tokens_per_image,
                                    reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_layernorm_patch2_nhwc(const float *x, int64_t n_img, int h, int w, int c, const float *gamma_or_null,
+                               const float *beta_or_null, float eps, float *y, void *stream) {
+    MIRX_CHECK(n_img >= 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "layernorm_patch2_nhwc: h and w must be even");
+    MIRX_CHECK(c >= 4 && c % 4 == 0 && c <= 8192, "layernorm_patch2_nhwc: c must be a multiple of 4, at most 8192");
+    MIRX_CHECK(n_img == 0 || (x && y), "layernorm_patch2_nhwc: null buffer");
+    MIRX_CHECK(x != y && eps >= 0.f, "layernorm_patch2_nhwc: not in place; eps must be non-negative");
+    MIRX_HIP(launch_layernorm_rows(x, n_img * h * w, c, gamma_or_null, beta_or_null, eps, y, 0, reinterpret_cast<hipStream_t>(stream),
+                                   nullptr, 1.f, w, h));
     return MIRX_OK;
 }
 
@@ -1164,6 +1203,16 @@ int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const 
     MIRX_CHECK(x_batch_stride >= (int64_t)cin * hw, "conv1x1: batch stride smaller than cin * hw");
     MIRX_HIP(launch_conv1x1(x, x_batch_stride, cin, scale, shift, wt, bias, n, hw, cout, relu_out, y,
                             reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_dwconv7x7_nhwc(const float *x, const float *w_taps_first, const float *bias, int64_t n, int c, int h, int wd, float *y,
+                        void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535 && c >= 1 && h >= 1 && wd >= 1, "dwconv7x7_nhwc: bad geometry (n <= 65535)");
+    MIRX_CHECK((int64_t)h * wd * c <= 0x7fffffff, "dwconv7x7_nhwc: one image must stay below 2^31 elements");
+    MIRX_CHECK(n == 0 || (x && w_taps_first && y), "dwconv7x7_nhwc: null buffer");
+    MIRX_CHECK(x != y, "dwconv7x7_nhwc: in place is not supported");
+    MIRX_HIP(launch_dwconv7_nhwc(x, w_taps_first, bias, n, c, h, wd, y, reinterpret_cast<hipStream_t>(stream)));
     return MIRX_OK;
 }
 

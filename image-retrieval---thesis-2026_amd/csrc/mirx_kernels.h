@@ -49,6 +49,8 @@ hipError_t launch_conv1x1(const float *x, int64_t xbs, int cin, const float *sca
                           hipStream_t st);
 
 // ---- k_convnext.hip ---------------------------------------------------------------------
+hipError_t launch_dwconv7_nhwc(const float *x, const float *wt, const float *bias, int64_t n, int c, int h, int wd, float *y,
+                               hipStream_t st);
 hipError_t launch_dwconv7(const float *x, const float *w, const float *bias, int64_t n, int c, int h, int wd,
                           float *y, hipStream_t st);
 // gx[b][c] = sqrt(sum over the hw positions of x[b][p][c]^2)       (x = [n][hw][c], channels last)
@@ -91,7 +93,9 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
                             const float *res, const float *gamma, float x_scale, float out_scale, float *y,
-                            int tokens_per_image, const float *xb_dev, hipStream_t st);
+                            int tokens_per_image, const float *xb_dev, hipStream_t st, bool rows_out = false,
+                            float *sq_out = nullptr);
+hipError_t launch_grn_norm_partials(const float *part, int tpi, int64_t n_img, int c, float *gx, hipStream_t st);
 
 // ---- k_linear_s3.hip ---------------------------------------------------------------------
 // tokens_per_image == 0: y / res are [m][n]; > 0: token t is pixel t % tpi of image t / tpi and y / res are NCHW
@@ -119,7 +123,8 @@ hipError_t launch_dense_fused(float *buf, int64_t bs, int cin, const float *scal
 
 // ---- k_norm.hip: LayerNorm over rows, patchify (+ LayerNorm2d), attention for short query sets ------------------
 hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *gamma, const float *beta, float eps,
-                                 float *y, int tokens_per_image, hipStream_t st, void *yt = nullptr, float scale = 1.f);
+                                 float *y, int tokens_per_image, hipStream_t st, void *yt = nullptr, float scale = 1.f,
+                                 int patch_w = 0, int patch_h = 0);
 // k_linear_t2.hip: the DMA-fed two-fp16-term Linear on "terms rows" and the fp32 -> terms conversion
 hipError_t launch_rows_to_terms(const float *x, int64_t m, int k, int64_t ldx, float scale, void *xt, hipStream_t st);
 hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, const float *bias, int n, int act,

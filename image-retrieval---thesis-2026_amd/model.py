@@ -100,6 +100,8 @@ class KernelConfig:
     conv3x3_legacy: tuple = ((56, "wino"), (28, "wino3"), (14, "direct3"), (7, "wino"))
     linear_three_bf16: bool = True          # token-major Linears on the MFMA kernels at all (False: rocBLAS fp32)
     linear_two_fp16: bool = True            #   .. on two fp16 terms where the input has a provable bound (LayerNorm outputs)
+    cnx_grn_in_fc1: bool = True             #   .. and fc1's epilogue returns the GRN norm's partial sums (no norm pass over the hidden map)
+    cnx_channels_last: bool = True          # ConvNeXtV2: the residual stream stays NHWC between blocks (no-LDS depthwise conv, row-major block tail)
     linear_terms_split_tail: bool = True    #   .. its last, partly filled round of tiles cut along K (mirx.h, mirx_linear_terms workspace)
     linear_terms_min_rows: int = 1024       #   .. ViT / SigLIP blocks with at least this many token rows: the DMA-fed Linear on pre-split
                                             #      "terms rows" (k_linear_t2: 256 x 256 tiles); 0 = never
@@ -785,15 +787,16 @@ class _ConvAsLinear:
     """A Conv2d whose kernel equals its stride (non-overlapping patches) seen as a Linear over patch rows: weight =
     conv.weight.flatten(1) zero-padded to a multiple of 16 input features (duck-typed for _linear_s3 / _linear_h2)."""
 
-    def __init__(self, conv):
+    def __init__(self, conv, channels_last=False):
         self.conv = conv
+        self.channels_last = channels_last            # feature order (ky, kx, c): patch rows gathered from an NHWC map
         self._key = None
 
     def refresh(self):
         w, b = self.conv.weight, self.conv.bias
         key = (w.data_ptr(), w._version, None if b is None else b._version)
         if key != self._key:
-            flat = w.detach().flatten(1)
+            flat = (w.detach().permute(0, 2, 3, 1) if self.channels_last else w.detach()).flatten(1)
             k = flat.shape[1]
             self.k = k
             self.in_features = (k + 15) // 16 * 16
@@ -1195,6 +1198,63 @@ class _CnxBlock(nn.Module):
             self._mirx_bias2 = cached
         return cached[1]
 
+    def _forward_nhwc(self, t, b, h, w):
+        """[HIP] The block on a channels-last residual stream t [b * h * w, c] (ConvNeXtV2 fast path): depthwise 7x7 without
+        LDS (a lane = a channel), LayerNorm, fc1 + GELU, GRN as a norm pass + a scale folded into fc2's staging, fc2 with the
+        skip added in its row-major epilogue.  -> the new stream (a fresh tensor)."""
+        lib = _lib.load()
+        mlp, c, dev = self.mlp, t.shape[-1], t.device
+        wk = self.conv_dw.weight
+        key = _tkey(wk)
+        cached = getattr(self, "_mirx_dw_t", None)
+        if cached is None or cached[0] != key:
+            cached = (key, wk.detach().reshape(c, 49).t().contiguous())          # [49][c]: a lane reads its channel's taps coalesced
+            self._mirx_dw_t = cached
+        y = torch.empty_like(t)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mirx_dwconv7x7_nhwc(_ptr(t), _ptr(cached[1]), _ptr(self.conv_dw.bias.detach()), b, c, h, w, _ptr(y),
+                                               _stream(dev)), "mirx_dwconv7x7_nhwc")
+        yn = _layernorm(self.norm, y)
+        bn = _layernorm_bound(self.norm)
+        c4 = mlp.fc1.out_features
+        gx = torch.empty((b, c4), dtype=torch.float32, device=dev)
+        fused_norm = h * w >= 128 and _cfg(self).cnx_grn_in_fc1
+        if fused_norm:
+            # fc1 + GELU returns the GRN partial sums of its own output tiles: the norm pass over the 4C-wide map disappears
+            w2f, wsf = _linear_h2_weights(mlp.fc1)
+            xs = _terms_scale(bn)
+            hid = torch.empty((b * h * w, c4), dtype=torch.float32, device=dev)   # [b * h * w, 4c]
+            parts = torch.empty(((b * h * w + 127) // 128) * 2 * c4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.mirx_linear_split2h_gelu_grn(_ptr(yn), b, h * w, c, _ptr(w2f), _ptr(mlp.fc1.bias.detach()), c4, xs,
+                                                            1.0 / (xs * wsf), _ptr(hid), _ptr(parts), _ptr(gx), _stream(dev)),
+                           "mirx_linear_split2h_gelu_grn")
+        else:
+            hid = _linear_h2(mlp.fc1, yn, bn, act=1)                              # [b * h * w, 4c]
+        scale = torch.empty_like(gx)
+        smax = torch.zeros(1, dtype=torch.float32, device=dev)
+        out = torch.empty_like(t)
+        w2, ws = _linear_h2_weights(mlp.fc2)
+        hb = _linear_out_bound(self.norm, mlp.fc1)                                # |gelu(fc1(LN(.)))| <= hb
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            if not fused_norm:
+                _lib.check(lib.mirx_grn_norm_nhwc(_ptr(hid), b, h * w, c4, _ptr(gx), st), "mirx_grn_norm_nhwc")
+            _lib.check(lib.mirx_grn_scale(_ptr(gx), _ptr(mlp.grn.weight.detach().reshape(-1).contiguous()), b, c4, 1e-6,
+                                          _ptr(scale), _ptr(smax), st), "mirx_grn_scale")
+            _lib.check(lib.mirx_linear_split2h_grn_rows(_ptr(hid), b, h * w, c4, _ptr(w2), _ptr(self._fc2_bias_with_grn_shift()), c,
+                                                        _ptr(t), _ptr(scale), float(hb), _ptr(smax), 1.0 / ws, _ptr(out), st),
+                       "mirx_linear_split2h_grn_rows")
+        return out
+
+    def _nhwc_ok(self):
+        mlp = self.mlp
+        bn = _layernorm_bound(self.norm)
+        hb = _linear_out_bound(self.norm, mlp.fc1)
+        probe = self.conv_dw.weight
+        return (_cfg(self).grn_scale_kernel and probe.is_cuda and self.conv_dw.bias is not None and mlp.fc1.bias is not None
+                and _linear_h2_ok(mlp.fc1, probe, bn) and _linear_h2_ok(mlp.fc2, probe, hb))
+
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32:
             # MI355X path: depthwise 7x7 + the NCHW->NHWC permute in one HIP pass
@@ -1312,7 +1372,51 @@ class _ConvNeXtV2Backbone(nn.Module):
             return _layernorm(self.stem[1], tok, tokens_per_image=(h // 4) * (w // 4)).view(b, -1, h // 4, w // 4)
         return self.stem(x)
 
+    def _forward_nhwc(self, x):
+        """[HIP] The whole backbone with a channels-last residual stream [b * h * w, c] (no NCHW map between the patch embedding
+        and the pooled head): stem = patch gather + MFMA Linear + LayerNorm rows; downsample = LayerNorm written straight into
+        2 x 2 patch rows + MFMA Linear (weight in (ky, kx, c) order); blocks = _CnxBlock._forward_nhwc."""
+        lib = _lib.load()
+        b, _, h, w = x.shape
+        dev = x.device
+        t = _layernorm(self.stem[1], _conv_patch_tokens(self.stem[0], x))                      # [b * h/4 * w/4, 128]
+        h, w = h // 4, w // 4
+        for stage in self.stages:
+            ds = stage.downsample
+            if isinstance(ds, nn.Sequential):
+                ln, conv = ds[0], ds[1]
+                pl = conv.__dict__.get("_mirx_as_linear_cl")
+                if pl is None:
+                    pl = _ConvAsLinear(conv, channels_last=True)
+                    conv.__dict__["_mirx_as_linear_cl"] = pl
+                pl.refresh()
+                c = t.shape[-1]
+                rows = torch.empty((b * (h // 2) * (w // 2), 4 * c), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.mirx_layernorm_patch2_nhwc(_ptr(t), b, h, w, c, _ptr(ln.weight.detach()), _ptr(ln.bias.detach()),
+                                                              float(ln.eps), _ptr(rows), _stream(dev)), "mirx_layernorm_patch2_nhwc")
+                h, w = h // 2, w // 2
+                bound = _layernorm_bound(ln)
+                t = _linear_h2(pl, rows, bound) if _linear_h2_ok(pl, rows, bound) else _linear_s3(pl, rows)
+            for blk in stage.blocks:
+                t = blk._forward_nhwc(t, b, h, w)
+        pooled = t.view(b, h * w, t.shape[-1]).mean(dim=1)                                    # global average pool
+        return _layernorm(self.head.norm, pooled)
+
+    def _nhwc_ok(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4 and x.shape[0] <= 65535):
+            return False
+        cfg = _cfg(self)
+        if not (cfg.cnx_channels_last and cfg.linear_three_bf16 and cfg.linear_two_fp16):
+            return False
+        h, w = x.shape[2], x.shape[3]
+        if h % 32 or w % 32:                                  # stem / 4, three downsamples / 2
+            return False
+        return all(blk._nhwc_ok() for stage in self.stages for blk in stage.blocks)
+
     def forward(self, x):
+        if self._nhwc_ok(x):
+            return self._forward_nhwc(x.contiguous())
         return self.head(self.stages(self._stem(x)))
 
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 302
+#define MIRX_VERSION 303
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -357,6 +357,11 @@ int mirx_linear_split2h(const float *x, int64_t m, int k, const void *w2, const 
  *                       order by a second launch -- deterministic for a given (m, k, n).  NULL = whole tiles only.
  */
 int mirx_rows_to_terms(const float *x, int64_t m, int k, int64_t row_stride, float scale, void *xt, void *stream);
+/* LayerNorm over the channels of every pixel of channels-last maps x [n_img, h, w, c], written as the 2 x 2 patch rows of a
+ * stride-2 convolution: y [n_img, h / 2, w / 2, 4 c] with feature order (ky, kx, channel) -- timm's LayerNorm2d + Conv2d(k = s = 2)
+ * downsample of ConvNeXt becomes this + a Linear whose weight is conv.weight.permute(0, 2, 3, 1).reshape(cout, 4 c). */
+int mirx_layernorm_patch2_nhwc(const float *x, int64_t n_img, int h, int w, int c, const float *gamma_or_null,
+                               const float *beta_or_null, float eps, float *y, void *stream);
 int mirx_layernorm_terms(const float *x, int64_t m, int c, const float *gamma_or_null, const float *beta_or_null, float eps,
                          float scale, void *yt, void *stream);
 int mirx_linear_terms(const void *xt, int64_t m, int k, const void *wt, const float *bias_or_null, int n, int act,
@@ -391,6 +396,19 @@ int mirx_linear_split2h_nchw(const float *x, int64_t n_img, int tokens_per_image
                              const float *bias_or_null, int n, const float *residual_or_null,
                              const float *input_scale_or_null, float x_bound, const float *input_scale_max_or_null,
                              float w_inv, float *y, void *stream);
+/* fc1 of a ConvNeXtV2 block with the global response norm's reduction folded in: y = gelu(mirx_linear_split2h(x)) (row-major
+ * [n_img * tokens_per_image, n]) AND gx[b, j] = || y[b, :, j] ||_2 (what mirx_grn_norm_nhwc would compute from y in a pass of its
+ * own): every workgroup returns the column sums of y^2 of its 128 token rows split by image in `partials` (device fp32,
+ * ceil(n_img * tokens_per_image / 128) * 2 * n floats), a second small launch adds them in tile order.  tokens_per_image >= 128.
+ * Bit-reproducible. */
+int mirx_linear_split2h_gelu_grn(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                                 const float *bias_or_null, int n, float x_scale, float out_scale, float *y, float *partials,
+                                 float *gx, void *stream);
+/* The same block tail for a channels-last residual stream (the ConvNeXtV2 fast path): residual and y are row-major
+ * [n_img * tokens_per_image, n] (y may alias the residual), input_scale / input_scale_max are required. */
+int mirx_linear_split2h_grn_rows(const float *x, int64_t n_img, int tokens_per_image, int k, const void *w2,
+                                 const float *bias_or_null, int n, const float *residual_or_null, const float *input_scale,
+                                 float x_bound, const float *input_scale_max, float w_inv, float *y, void *stream);
 
 /*
  * Global response normalisation of ConvNeXtV2 (timm GlobalResponseNorm, channels last) as two HBM passes:
@@ -567,6 +585,11 @@ int mirx_conv1x1_bn_relu(const float *x, int64_t x_batch_stride, int cin, const 
  */
 int mirx_dwconv7x7_nchw_to_nhwc(const float *x, const float *w, const float *bias, int64_t n, int c, int h,
                                 int wd, float *y, void *stream);
+/* The same convolution on a channels-last map (the ConvNeXtV2 fast path keeps its residual stream NHWC): x, y = device NHWC fp32
+ * [n, h, w, c] (y != x); w_taps_first = device [49][c] (conv_dw.weight.view(c, 49).t(), prepared once per layer); bias [c] or
+ * NULL.  No LDS: a lane owns one channel and walks a strip of 4 output rows with a 7-column window in registers. */
+int mirx_dwconv7x7_nhwc(const float *x, const float *w_taps_first, const float *bias, int64_t n, int c, int h, int wd, float *y,
+                        void *stream);
 
 #ifdef __cplusplus
 }
