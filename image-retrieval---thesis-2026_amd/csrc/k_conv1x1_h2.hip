@@ -212,11 +212,25 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
         // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
         C1_STAMP(st_store)
+#ifdef MIRX_C1H2_COUNTED
+        // experiment (round 3): wait only for the two DMA pieces -- the OLDEST operations in flight -- and leave the 8 NPT
+        // activation loads issued behind them in flight across the barrier.  tools/dma_order_probe.hip (5e8 words per variant,
+        // cold and hot DMA sources, loads behind them missing to HBM) finds a counted wait SAFE when program order is fenced
+        // (the sched_barrier between dma_w and load below): round 2's state-dependent errors were most likely loads hoisted
+        // above the DMA pieces.  State probe and the whole model suite are clean with it.  Measured: -2.7 % on the layers back to
+        // back, 45.2-45.4 k img/s either way on the whole forward -- not adopted, the drain is not what holds the layer.
+        if (NPT == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        C1_STAMP(st_wait)
+        __builtin_amdgcn_s_barrier();
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C1_STAMP(st_wait)
         __syncthreads();
+#endif
         C1_STAMP(st_bar)
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
+        __builtin_amdgcn_sched_barrier(0);                 // (the DMA pieces stay older than the loads behind them)
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
         C1_STAMP(st_issue)
