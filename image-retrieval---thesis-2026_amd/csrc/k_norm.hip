@@ -36,13 +36,22 @@ __device__ inline float wave_sum(float v) {
 // the input format of the DMA-fed Linear) instead of fp32 -- the same bytes, and the Linear that follows needs no split.
 // The row is read ONCE and kept in registers (RV 16-byte vectors per lane: c <= 256 RV features; the launcher picks RV): mean,
 // variance (two passes over the registers, the reference's formula) and the result come from the same loads.
-template <bool TERMS, int RV>
+// LW = lanes per row: 64, or 32 for rows of at most 128 features (two rows per wavefront -- with 64 lanes half of them
+// would idle on ConvNeXtV2's 128-channel maps, its largest LayerNorms by bytes); reductions stay inside the LW lanes.
+template <int LW>
+__device__ inline float row_sum(float v) {
+#pragma unroll
+    for (int off = LW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool TERMS, int RV, int LW = 64>
 __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict__ x, int64_t m, int c,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float eps, float *__restrict__ y, char *__restrict__ yt, float scale,
                                                         int cp, int patch_w, int patch_h) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & (LW - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / LW) + threadIdx.x / LW;
     if (row >= m) return;
     const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * c);
     const int nv = c >> 2;
@@ -50,20 +59,20 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict_
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < RV; ++j) {
-        const int i = lane + 64 * j;
+        const int i = lane + LW * j;
         v[j] = i < nv ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
-    const float mean = wave_sum(s) / (float)c;
+    const float mean = row_sum<LW>(s) / (float)c;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < RV; ++j) {
-        if (lane + 64 * j < nv) {
+        if (lane + LW * j < nv) {
             const float d0 = v[j][0] - mean, d1 = v[j][1] - mean, d2 = v[j][2] - mean, d3 = v[j][3] - mean;
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+    const float rstd = 1.0f / sqrtf(row_sum<LW>(q) / (float)c + eps);
     // patch_w > 0: the rows are the pixels of channels-last maps [image][patch_h][patch_w][c] and the result goes to the
     // 2 x 2 patch rows of a stride-2 convolution, [image][patch_h / 2][patch_w / 2][(ky, kx, c)] (ConvNeXt downsample)
     int64_t orow = row * c;
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(256) void k_layernorm_rows(const float *__restrict_
     char *tr = yt + row * ((int64_t)cp * 4);
 #pragma unroll
     for (int j = 0; j < RV; ++j) {
-        const int i = lane + 64 * j;
+        const int i = lane + LW * j;
         if (i >= (TERMS ? cp >> 2 : nv)) continue;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (i < nv) {
@@ -264,6 +273,11 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
         if (cp > 8192) return hipErrorInvalidValue;
 #define MIRX_LNT(RV) hipLaunchKernelGGL((k_layernorm_rows<true, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
                                         nullptr, reinterpret_cast<char *>(yt), scale, cp, 0, 0)
+        if (cp <= 128) {
+            hipLaunchKernelGGL((k_layernorm_rows<true, 1, 32>), dim3((unsigned)((m + 7) / 8)), dim3(256), 0, st, x, m, c, gamma, beta, eps,
+                               nullptr, reinterpret_cast<char *>(yt), scale, cp, 0, 0);
+            return hipGetLastError();
+        }
         if (cp <= 512) MIRX_LNT(2); else if (cp <= 1024) MIRX_LNT(4); else if (cp <= 2048) MIRX_LNT(8); else if (cp <= 4096) MIRX_LNT(16); else MIRX_LNT(32);
 #undef MIRX_LNT
         return hipGetLastError();
@@ -282,6 +296,11 @@ hipError_t launch_layernorm_rows(const float *x, int64_t m, int c, const float *
         if (c > 8192) return hipErrorInvalidValue;
 #define MIRX_LN(RV) hipLaunchKernelGGL((k_layernorm_rows<false, RV>), dim3((unsigned)blocks), dim3(256), 0, st, x, m, c, gamma, beta, eps, \
                                        y, nullptr, 1.f, 0, patch_w, patch_h)
+        if (c <= 128) {
+            hipLaunchKernelGGL((k_layernorm_rows<false, 1, 32>), dim3((unsigned)((m + 7) / 8)), dim3(256), 0, st, x, m, c, gamma, beta, eps,
+                               y, nullptr, 1.f, 0, patch_w, patch_h);
+            return hipGetLastError();
+        }
         if (c <= 512) MIRX_LN(2); else if (c <= 1024) MIRX_LN(4); else if (c <= 2048) MIRX_LN(8); else if (c <= 4096) MIRX_LN(16); else MIRX_LN(32);
 #undef MIRX_LN
     }
