@@ -136,12 +136,15 @@ __global__ __launch_bounds__(32 * (DT / RPT), 2) void k_dwconv7(const float *__r
 
 // ---- depthwise 7x7 on a channels-last map (NHWC in, NHWC out): no LDS, no staging phase ---------------------------------
 // With channels last, a wavefront's lanes are 64 consecutive channels of one pixel: every load and store is one 256-byte
-// run, and a thread (one channel) can walk a strip of DR output rows along x with a 7-column window of its DR + 6 input
+// run, and a thread (one channel) can walk a strip of DR = 3 output rows along x with a 7-column window of its DR + 6 input
 // rows in registers: a step loads ONE new column (DR + 6 values), multiplies the whole window (DR x 49 FMAs) and stores DR
 // outputs.  The window rotates by renaming (the x loop is unrolled by 7), an input value is fetched (DR + 6) / DR times
 // (from L2 after the first), weights arrive as [49][c] (transposed once on the host side of the model) in 49 registers.
 // grid: (ceil(h / DR) strips, ceil(c / 64), n); block: 64.
-constexpr int DR = 4;
+#ifndef MIRX_DW_DR
+#define MIRX_DW_DR 3
+#endif
+constexpr int DR = MIRX_DW_DR;      // output rows per thread (ConvNeXtV2 @384, B = 64, same box: 2 / 3 / 4 / 6 / 8 rows -> 1 960 / 2 024 / 2 010 / 1 897 / 1 848 img/s)
 
 __global__ __launch_bounds__(64) void k_dwconv7_nhwc(const float *__restrict__ x, const float *__restrict__ wt,
                                                      const float *__restrict__ bias, int c, int h, int wd,

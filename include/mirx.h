@@ -587,7 +587,7 @@ int mirx_dwconv7x7_nchw_to_nhwc(const float *x, const float *w, const float *bia
                                 int wd, float *y, void *stream);
 /* The same convolution on a channels-last map (the ConvNeXtV2 fast path keeps its residual stream NHWC): x, y = device NHWC fp32
  * [n, h, w, c] (y != x); w_taps_first = device [49][c] (conv_dw.weight.view(c, 49).t(), prepared once per layer); bias [c] or
- * NULL.  No LDS: a lane owns one channel and walks a strip of 4 output rows with a 7-column window in registers. */
+ * NULL.  No LDS: a lane owns one channel and walks a strip of 3 output rows with a 7-column window in registers. */
 int mirx_dwconv7x7_nhwc(const float *x, const float *w_taps_first, const float *bias, int64_t n, int c, int h, int wd, float *y,
                         void *stream);
 
