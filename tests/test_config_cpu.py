@@ -105,3 +105,21 @@ def test_default_transform_is_the_float32_arithmetic_of_totensor_and_normalize()
     want = (x - torch.tensor(IMAGENET_MEAN).view(3, 1, 1)) / torch.tensor(IMAGENET_STD).view(3, 1, 1)
     assert got.dtype == torch.float32 and got.shape == (3, 224, 224) and got.is_contiguous()
     assert torch.equal(got, want)
+
+
+def test_channels_last_patch_rows_reproduce_the_stride2_convolution():
+    """Host side of ConvNeXtV2's channels-last downsample: patch rows in (ky, kx, c) order (what mirx_layernorm_patch2_nhwc writes)
+    times _ConvAsLinear(conv, channels_last=True).weight is the Conv2d(kernel = stride = 2) of the NCHW map."""
+    import mirx.model as mm
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(24, 40, kernel_size=2, stride=2)
+    x = torch.randn(2, 24, 6, 8)
+    want = conv(x).permute(0, 2, 3, 1).reshape(-1, 40)                                        # [b * 3 * 4, 40] rows
+    t = x.permute(0, 2, 3, 1).contiguous()                                                    # NHWC
+    rows = t.view(2, 3, 2, 4, 2, 24).permute(0, 1, 3, 2, 4, 5).reshape(2 * 3 * 4, 4 * 24)      # (ky, kx, c) per patch
+    pl = mm._ConvAsLinear(conv, channels_last=True).refresh()
+    assert pl.in_features == 96 and pl.out_features == 40
+    got = rows @ pl.weight.t() + pl.bias
+    assert float((got - want).abs().max()) < 1e-5
+    plain = mm._ConvAsLinear(conv).refresh()                                                  # (c, ky, kx): the NCHW patch gather's order
+    assert not torch.equal(plain.weight, pl.weight)
