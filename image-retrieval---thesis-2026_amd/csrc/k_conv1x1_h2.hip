@@ -35,7 +35,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 // Diagnostic build -DMIRX_C1H2_STAMPS: s_memtime at the phase boundaries of every stage, wave 0 of each workgroup, into
 // g_c1_stamps (read back by tools/bench_conv1x1.py --stamps through mirx_debug_c1_stamps); never in the shipped library.
 #ifdef MIRX_C1H2_STAMPS
-__device__ unsigned long long g_c1_stamps[8192 * 8];
+__device__ unsigned long long g_c1_stamps[8192 * 8];      // [7] = (store total << 32) | (its VALU part)
 #define C1_STAMP(ACC)                                                 \
     {                                                                 \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -149,6 +149,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
             }
         }
     };
+#ifdef MIRX_C1H2_STAMPS
+    unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_store = 0, st_valu = 0;
+    const unsigned long long st_begin = st_t, rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     auto store = [&](int buf, const float (&r)[NPT][NR], const float (&rsc)[8], const float (&rsh)[8]) {
         char *sb = sm + buf * STAGE_N;
 #pragma unroll
@@ -165,10 +169,25 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     v[1] = fmaxf(fmaf(v[1], rsc[2 * j + 1], rsh[2 * j + 1]), 0.f);
                 }
                 unsigned th, tl;
+#if defined(MIRX_C1H2_EXP_SPLIT) && MIRX_C1H2_EXP_SPLIT == 0        // diagnostic (wrong results): no BN / ReLU / split arithmetic at all
+                th = __float_as_uint(r[u][2 * j]);
+                tl = __float_as_uint(r[u][2 * j + 1]);
+#elif defined(MIRX_C1H2_EXP_SPLIT) && MIRX_C1H2_EXP_SPLIT == 1      // diagnostic (wrong results): BN / ReLU / scale kept, the fp16 split dropped
+                th = __float_as_uint(v[0] * x_scale[u]);
+                tl = __float_as_uint(v[1] * x_scale[u]);
+#else
                 split2h_pair(v[0] * x_scale[u], v[1] * x_scale[u], th, tl);
+#endif
                 ph[j] = th;
                 pl[j] = tl;
             }
+#ifdef MIRX_C1H2_STAMPS
+            if (u == NPT - 1) {                              // (diagnostic: everything of `store` but the last two LDS writes)
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                C1_STAMP(st_valu)
+            }
+#endif
             *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B) = ph;
             *reinterpret_cast<u32x4 *>(sb + b_lds + u * 2 * PLANE_B + PLANE_B) = pl;
         }
@@ -198,10 +217,6 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-#ifdef MIRX_C1H2_STAMPS
-    unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_store = 0;
-    const unsigned long long st_begin = st_t, rt_begin = __builtin_amdgcn_s_memrealtime();
-#endif
     // one stage: LDS buffer `cur` holds stage kt; `rnext` receives stage kt + 2; `rstore` holds stage kt + 1
     auto stage = [&](int kt, int cur, float (&rnext)[NPT][NR], float (&scn)[8], float (&shn)[8], const float (&rstore)[NPT][NR],
                      const float (&scs)[8], const float (&shs)[8]) {
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         o[4] = st_bar;
         o[5] = st_issue;
         o[6] = st_mfma;
-        o[7] = st_store;
+        o[7] = (st_store << 32) | (st_valu & 0xffffffffull);          // st_store excludes the part already counted in st_valu
     }
 #endif
 

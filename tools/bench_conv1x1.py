@@ -74,12 +74,16 @@ def main():
                 dbg = ctypes.CDLL(_lib.LIB_PATH)
                 sb = np.zeros(8192 * 8, dtype=np.uint64)
                 assert dbg.mirx_debug_c1_stamps(sb.ctypes.data_as(ctypes.c_void_p)) == 0
-                t = sb.reshape(8192, 8).astype(np.float64)
-                t = t[t[:, 2] > 0]
+                t8 = sb.reshape(8192, 8)
+                valu = (t8[:, 7] & np.uint64(0xffffffff)).astype(np.float64)
+                t = t8.astype(np.float64)
+                t[:, 7] = (t8[:, 7] >> np.uint64(32)).astype(np.float64)
+                keep = t[:, 2] > 0
+                t, valu = t[keep], valu[keep]
                 nk_ = t[:, 2]
                 md = lambda v: float(np.median(v))      # noqa: E731
                 print(f"   stamps (last layer, cin {layers[-1][0]}, {len(t)} wgs): K loop {md(t[:, 0] / nk_):.0f} cycles/stage = wait {md(t[:, 3] / nk_):.0f} "
-                      f"+ barrier {md(t[:, 4] / nk_):.0f} + issue {md(t[:, 5] / nk_):.0f} + frags/mfma {md(t[:, 6] / nk_):.0f} + split/store {md(t[:, 7] / nk_):.0f}; "
+                      f"+ barrier {md(t[:, 4] / nk_):.0f} + issue {md(t[:, 5] / nk_):.0f} + frags/mfma {md(t[:, 6] / nk_):.0f} + BN / ReLU / split {md(valu / nk_):.0f} + LDS stores and the rest {md(t[:, 7] / nk_):.0f}; "
                       f"clock {md(t[:, 0] / t[:, 1] * 100):.0f} MHz", flush=True)
         del buf, y
     print(f"total s3 {tot['s3']:.2f} ms, h2 {tot['h2']:.2f} ms per {a.batch} images")

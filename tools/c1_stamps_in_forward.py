@@ -43,14 +43,18 @@ def main():
     dbg = ctypes.CDLL(_lib.LIB_PATH)
     sb = np.zeros(8192 * 8, dtype=np.uint64)
     assert dbg.mirx_debug_c1_stamps(sb.ctypes.data_as(ctypes.c_void_p)) == 0
-    t = sb.reshape(8192, 8).astype(np.float64)
-    t = t[t[:, 2] > 0]
+    t8 = sb.reshape(8192, 8)
+    valu = (t8[:, 7] & np.uint64(0xffffffff)).astype(np.float64)
+    t = t8.astype(np.float64)
+    t[:, 7] = (t8[:, 7] >> np.uint64(32)).astype(np.float64)
+    keep = t[:, 2] > 0
+    t, valu = t[keep], valu[keep]
     nk = t[:, 2]
     md = lambda v: float(np.median(v))      # noqa: E731
     print(f"forward of 4096 images on two streams: {dt * 1e3:.1f} ms = {4096 / dt:.0f} img/s (stamped build)")
     print(f"k_conv1x1_h2 stamps (whatever launches wrote last, {len(t)} workgroups, stages per workgroup median {md(nk):.0f}): "
           f"{md(t[:, 0] / nk):.0f} cycles/stage = wait {md(t[:, 3] / nk):.0f} + barrier {md(t[:, 4] / nk):.0f} + issue {md(t[:, 5] / nk):.0f} "
-          f"+ frags/mfma {md(t[:, 6] / nk):.0f} + split/store {md(t[:, 7] / nk):.0f}; clock median {md(t[:, 0] / t[:, 1] * 100):.0f} MHz, "
+          f"+ frags/mfma {md(t[:, 6] / nk):.0f} + BN / ReLU / split {md(valu / nk):.0f} + LDS stores and the rest {md(t[:, 7] / nk):.0f}; clock median {md(t[:, 0] / t[:, 1] * 100):.0f} MHz, "
           f"10th / 90th percentile {float(np.percentile(t[:, 0] / t[:, 1] * 100, 10)):.0f} / {float(np.percentile(t[:, 0] / t[:, 1] * 100, 90)):.0f}")
 
 
