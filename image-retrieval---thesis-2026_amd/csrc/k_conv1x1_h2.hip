@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         __syncthreads();
 #endif
         C1_STAMP(st_bar)
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 1)          // diagnostic (wrong results): no weight DMA inside the K loop
+        if (kt < 0)
+#endif
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
         __builtin_amdgcn_sched_barrier(0);                 // (the DMA pieces stay older than the loads behind them)
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
@@ -339,6 +342,9 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     }
 #endif
 
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 2)          // diagnostic (wrong results): nothing is written
+    if (in_ks > -1e30f) return;
+#endif
     // epilogue: register r of tile (mi, ni) = channel co0 + 64 wm + 32 mi + (r&3) + 8 (r>>2) + 4 (lane>>5),
     // pixel p0 + 128 (ni >> 1) + 64 wn + 32 (ni & 1) + (lane & 31)
     // per accumulator tile column: this lane's pixel, its image and that image's scales (oscale and 2^-s are powers of two,
@@ -372,16 +378,29 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     for (int e = 0; e < 2; ++e) {
                         const int r = 2 * j + e;
                         const int ch = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 8)          // diagnostic: the epilogue's stores without its arithmetic
+                        v[e] = acc[mi][ni][r];
+                        (void)ch;
+#else
                         float t = fmaf(acc[mi][ni][r], TABLED ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv, sBias[ch]);
                         t = t < 0.f ? 0.f : t;
                         v[e] = t * y_scale;
+#endif
                     }
                     unsigned hh, ll;
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 8)
+                    hh = __float_as_uint(v[0]);
+                    ll = __float_as_uint(v[1]);
+#else
                     split2h_pair(v[0], v[1], hh, ll);
+#endif
                     if (j < 4) { h0[j] = hh; l0[j] = ll; }
                     else { h1[j - 4] = hh; l1[j - 4] = ll; }
                 }
                 uint16_t *dst = yt + (((bimg * 8 + g) * 2) * (int64_t)hw + off) * 16;
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 4)          // diagnostic: the epilogue's arithmetic without its stores
+                if ((h0[0] ^ h1[1] ^ l0[2] ^ l1[3]) != 0x5a5a1234u) continue;
+#endif
                 *reinterpret_cast<u32x4 *>(dst) = h0;
                 *reinterpret_cast<u32x4 *>(dst + 8) = h1;
                 *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = l0;
