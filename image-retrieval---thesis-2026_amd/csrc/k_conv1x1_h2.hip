@@ -64,6 +64,33 @@ constexpr int PLANE_B = CP * KC * 2;
 // accumulator registers per lane (two workgroups per CU instead of three).
 // TABLED: the images a workgroup's pixels can span fit the 8-row oscale table (hw >= 37 with two pixel tiles) -- decided by the
 // launcher, so that the epilogue holds ONE form of the multiply (a run-time choice made the compiler emit both for every value)
+// Lanes 2 j and 2 j + 1 exchange half of what they hold: a = (even lane) its own p, (odd lane) the even neighbour's q;
+// b = (even lane) the odd neighbour's p, (odd lane) its own q.  One v_cndmask_b32_dpp per word (D = vcc ? src1 : dpp(src0));
+// written out because the compiler turns the same thing in C into a select, a v_mov_b32_dpp and two more selects per word.
+// The s_nop covers the two wait states a DPP read needs behind the VALU write of its source (the hazard recogniser does not
+// look into inline assembly).
+__device__ __forceinline__ void pair_exchange(const u32x4 &p, const u32x4 &q, u32x4 &a, u32x4 &b) {
+    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+    asm volatile("s_nop 1\n"
+                 "s_mov_b64 vcc, %[me]\n"
+                 "v_cndmask_b32_dpp %[a0], %[q0], %[p0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[a1], %[q1], %[p1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[a2], %[q2], %[p2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[a3], %[q3], %[p3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_mov_b64 vcc, %[mo]\n"
+                 "v_cndmask_b32_dpp %[b0], %[p0], %[q0], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[b1], %[p1], %[q1], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[b2], %[p2], %[q2], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_dpp %[b3], %[p3], %[q3], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1),
+                   [b2] "=&v"(b2), [b3] "=&v"(b3)
+                 : [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [q0] "v"(q[0]), [q1] "v"(q[1]),
+                   [q2] "v"(q[2]), [q3] "v"(q[3]), [me] "s"(0x5555555555555555ull), [mo] "s"(0xaaaaaaaaaaaaaaaaull)
+                 : "vcc");
+    a = u32x4{a0, a1, a2, a3};
+    b = u32x4{b0, b1, b2, b3};
+}
+
 template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED>
 __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
@@ -78,6 +105,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     extern __shared__ __attribute__((aligned(16))) char sm[];
     constexpr int KIMG = 8;                        // images a workgroup's pixels may span with a table row each (else: multiply)
     __shared__ float sBias[CM], sOsc[KIMG][CM];
+    // YTERMS with a table: the image's output scale 2^t is folded into BOTH constants of the epilogue's multiply-add (a power of
+    // two: fma(a, s 2^t, b 2^t) = 2^t fma(a, s, b) exactly), which takes one multiply per value out of the epilogue
+    constexpr bool YFOLD = YTERMS && TABLED;
+    __shared__ float sBiasY[YFOLD ? KIMG : 1][CM];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
@@ -110,7 +141,18 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         st_img[u] = pimg;
         xsrc[u] = x + b_off + (int64_t)(8 * b_kg) * in_hw;
     }
-    const int b_lds = 2 * PLANE_A + b_px * 32 + ((b_kg ^ ((b_px >> 3) & 1)) << 4);     // + tile * 2 PLANE_B + term * PLANE_B
+    // YTERMS: within every block of 32 pixels, pixel p is staged into LDS row ((p & 15) << 1) | (p >> 4), so that accumulator
+    // column l (which reads row l) is pixel 16 (l & 1) + (l >> 1): the lanes 2 j and 2 j + 1 hold the pixels j and 16 + j, and
+    // after a swap between those two neighbours every store instruction of the epilogue writes whole 32-byte pixel records, 512
+    // contiguous bytes per half-wave (with the pixels in lane order each instruction wrote 16 bytes of every 32: -5 % on the
+    // whole forward).  The ds_write below then lands two rows of a bank group per 16 lanes.
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 32)         // diagnostic (pixels land in the wrong records): the rows in pixel order
+    const int b_row = b_px;
+#else
+    const int b_row = YTERMS ? ((b_px & ~31) | ((b_px & 15) << 1) | ((b_px >> 4) & 1)) : b_px;
+#endif
+    const int b_lds = 2 * PLANE_A + b_row * 32 + ((b_kg ^ ((b_row >> 3) & 1)) << 4);   // + tile * 2 PLANE_B + term * PLANE_B
+    const int ep_px = YTERMS ? 16 * (lane & 1) + ((lane & 31) >> 1) : (lane & 31);     // this lane's pixel within its 32-block
     // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
     // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
     // l / 2, slot l & 1), which holds source chunk (l & 1) ^ ((row >> 3) & 1) -- the same for every piece.
@@ -290,8 +332,12 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
             const unsigned nimg = p_last / (unsigned)hw - img_first + 1;
             for (unsigned k = 0; k < nimg; ++k) {
                 float xs_, xi_;
-                range_scales(image_bound(img_first + k), xs_, xi_);
-                sOsc[k][threadIdx.x] = osc * xi_;                       // two powers of two: exact
+                const float xb_ = image_bound(img_first + k);
+                range_scales(xb_, xs_, xi_);
+                float ys_ = 1.f, yi_;
+                if (YFOLD) range_scales(fmaf(y_ks, xb_, y_kb), ys_, yi_);
+                sOsc[k][threadIdx.x] = osc * xi_ * ys_;                 // powers of two: exact
+                if (YFOLD) sBiasY[k][threadIdx.x] = sBias[threadIdx.x] * ys_;
             }
         }
     }
@@ -308,7 +354,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     int ep_k[NN];
 #pragma unroll
     for (int ni = 0; ni < NN; ++ni) {
-        unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31));
+        unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + ep_px);
         if (pp >= (unsigned)total) pp = (unsigned)total - 1u;
         const unsigned pimg = pp / (unsigned)hw;
         const float xb = image_bound(pimg);
@@ -355,18 +401,27 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         // permuted to the same channel order: mirx.model.YTERMS_CHANNEL_ORDER): a lane writes 32 contiguous bytes per term,
         // a half-wave 1 KiB
         uint16_t *yt = reinterpret_cast<uint16_t *>(y);
+        // the neighbour's value (lanes 2 j <-> 2 j + 1)
+        auto nb = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
+        const bool even = !(lane & 1);
 #pragma unroll
         for (int ni = 0; ni < NN; ++ni) {
-            const unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + (lane & 31));
-            if (pp >= (unsigned)total) continue;
-            const unsigned ubimg = pp / (unsigned)hw;
-            const int64_t bimg = ubimg, off = pp - ubimg * (unsigned)hw;
-            const float x_inv = ep_xinv[ni], y_scale = ep_ys[ni];
-            if (off == 0 && wm == 0 && lane < 32) {                            // one writer per image: the lane of its pixel 0
+            const unsigned pp = (unsigned)(p0 + (ni >> 1) * CP + wn * 64 + 32 * (ni & 1) + ep_px);
+            const bool live = pp < (unsigned)total;
+            const unsigned ubimg = (live ? pp : 0u) / (unsigned)hw;
+            const int64_t bimg = ubimg;
+            const unsigned off = pp - ubimg * (unsigned)hw;
+            if (live && off == 0 && wm == 0 && lane < 32) {                    // one writer per image: the lane of its pixel 0
                 float ys_, y_inv;
                 range_scales(fmaf(y_ks, image_bound(bimg), y_kb), ys_, y_inv);
                 y_inv_out[bimg] = y_inv;
             }
+            // this pixel's record of group 0, term 0, in records of 32 bytes (fits 32 bits: the launcher checks n hw < 2^27)
+            // instruction A writes the even lane's pixel, instruction B the odd lane's: both lanes of a pair need both
+            const unsigned q_own = live ? ubimg * 16u * (unsigned)hw + off : 0xffffffffu;
+            const unsigned q_nb = nb(q_own);
+            const unsigned qa = even ? q_own : q_nb, qb = even ? q_nb : q_own;
+            [[maybe_unused]] const float x_inv = ep_xinv[ni], y_scale = ep_ys[ni];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int g = 4 * wm + 2 * mi + (lane >> 5);
@@ -382,9 +437,12 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                         v[e] = acc[mi][ni][r];
                         (void)ch;
 #else
-                        float t = fmaf(acc[mi][ni][r], TABLED ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv, sBias[ch]);
-                        t = t < 0.f ? 0.f : t;
-                        v[e] = t * y_scale;
+                        float t = fmaf(acc[mi][ni][r], TABLED ? sOsc[ep_k[ni]][ch] : sOsc[0][ch] * x_inv,
+                                       YFOLD ? sBiasY[ep_k[ni]][ch] : sBias[ch]);
+                        // ReLU on the bits: a negative float is a negative integer (one v_max_i32 instead of compare + select
+                        // and their VCC wait states; -0 becomes +0, a NaN keeps its bits unless its sign bit is set)
+                        t = __int_as_float(max(__float_as_int(t), 0));
+                        v[e] = YFOLD ? t : t * y_scale;
 #endif
                     }
                     unsigned hh, ll;
@@ -397,14 +455,25 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                     if (j < 4) { h0[j] = hh; l0[j] = ll; }
                     else { h1[j - 4] = hh; l1[j - 4] = ll; }
                 }
-                uint16_t *dst = yt + (((bimg * 8 + g) * 2) * (int64_t)hw + off) * 16;
-#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 4)          // diagnostic: the epilogue's arithmetic without its stores
+#if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 4)          // diagnostic: (a quarter of) the epilogue's arithmetic without its stores
                 if ((h0[0] ^ h1[1] ^ l0[2] ^ l1[3]) != 0x5a5a1234u) continue;
 #endif
-                *reinterpret_cast<u32x4 *>(dst) = h0;
-                *reinterpret_cast<u32x4 *>(dst + 8) = h1;
-                *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = l0;
-                *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16 + 8) = l1;
+                // even lane: channels 0-7 of its own pixel (A) and of its neighbour's (B); odd lane: channels 8-15 of both
+                u32x4 ah, al, bh, bl;
+                pair_exchange(h0, h1, ah, bh);
+                pair_exchange(l0, l1, al, bl);
+                const int64_t gofs = (int64_t)(2 * g) * hw;                    // records from group 0 to group g
+                const int half = (lane & 1) * 8;
+                if (qa != 0xffffffffu) {
+                    uint16_t *dst = yt + ((int64_t)qa + gofs) * 16 + half;
+                    *reinterpret_cast<u32x4 *>(dst) = ah;
+                    *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = al;
+                }
+                if (qb != 0xffffffffu) {
+                    uint16_t *dst = yt + ((int64_t)qb + gofs) * 16 + half;
+                    *reinterpret_cast<u32x4 *>(dst) = bh;
+                    *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = bl;
+                }
             }
         }
         return;
@@ -458,6 +527,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     // two pixel tiles per workgroup (one staged copy of the weights for both) when the launch still fills the chip
     const int64_t px = n * (int64_t)hw;
     if (px >= ((int64_t)1 << 31) - 2 * CP) return hipErrorInvalidValue;      // the kernel indexes pixels with 32 bits
+    if (yterms && px >= ((int64_t)1 << 27)) return hipErrorInvalidValue;     // ... and the 32-byte records of y (16 per pixel) too
     const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
     const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
     const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
