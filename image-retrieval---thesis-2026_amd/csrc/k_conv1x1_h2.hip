@@ -464,16 +464,24 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                 pair_exchange(l0, l1, al, bl);
                 const int64_t gofs = (int64_t)(2 * g) * hw;                    // records from group 0 to group g
                 const int half = (lane & 1) * 8;
+                // (-DMIRX_C1H2_NT_STORES, non-temporal stores for these records that no workgroup reads back: 90.6-91.0 ms either
+                // way on one box -- kept as the A/B arm)
+#ifdef MIRX_C1H2_NT_STORES
+#define C1_ST(P, V) __builtin_nontemporal_store(V, reinterpret_cast<u32x4 *>(P))
+#else
+#define C1_ST(P, V) *reinterpret_cast<u32x4 *>(P) = V
+#endif
                 if (qa != 0xffffffffu) {
                     uint16_t *dst = yt + ((int64_t)qa + gofs) * 16 + half;
-                    *reinterpret_cast<u32x4 *>(dst) = ah;
-                    *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = al;
+                    C1_ST(dst, ah);
+                    C1_ST(dst + (int64_t)hw * 16, al);
                 }
                 if (qb != 0xffffffffu) {
                     uint16_t *dst = yt + ((int64_t)qb + gofs) * 16 + half;
-                    *reinterpret_cast<u32x4 *>(dst) = bh;
-                    *reinterpret_cast<u32x4 *>(dst + (int64_t)hw * 16) = bl;
+                    C1_ST(dst, bh);
+                    C1_ST(dst + (int64_t)hw * 16, bl);
                 }
+#undef C1_ST
             }
         }
         return;
