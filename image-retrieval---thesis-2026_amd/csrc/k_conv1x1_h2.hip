@@ -159,13 +159,14 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)), 0, nk * (2 * CM * KC * 2), 0x00020000);
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
+    [[maybe_unused]] auto dma_w1 = [&](int kt, int buf, int i) {
+        const int piece = wave + 4 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE_N + piece * 1024), 16, w_voff,
+                                                 kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
+    };
     [[maybe_unused]] auto dma_w = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wave + 4 * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE_N + piece * 1024), 16, w_voff,
-                                                     kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
-        }
+        dma_w1(kt, buf, 0);
+        dma_w1(kt, buf, 1);
     };
 
     // (An arm with the weights through registers -- plain loads + ds_write_b128, so that hipcc's counted s_waitcnt keeps two
@@ -286,11 +287,13 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         __syncthreads();
 #endif
         C1_STAMP(st_bar)
+#ifndef MIRX_C1H2_DMA_SPREAD
 #if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 1)          // diagnostic (wrong results): no weight DMA inside the K loop
         if (kt < 0)
 #endif
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
         __builtin_amdgcn_sched_barrier(0);                 // (the DMA pieces stay older than the loads behind them)
+#endif
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
         C1_STAMP(st_issue)
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
             for (int p = 0; p < 2; ++p)
                 b[ni][p] = *reinterpret_cast<const f16x8 *>(sb + fb[ni & 1] + (ni >> 1) * 2 * PLANE_B + p * PLANE_B);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < NN; ++ni) {
                 f32x16 c = acc[mi][ni];
@@ -318,6 +321,16 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], c, 0, 0, 0);
                 acc[mi][ni] = c;
             }
+#ifdef MIRX_C1H2_DMA_SPREAD
+            // the A/B arm: a wave's issue stalls on every `buffer_load ... lds` piece; behind a row of MFMAs already queued the
+            // stall costs the matrix pipe nothing (as in k_gemm16), right behind the barrier it delays the whole stage.
+            // Measured SLOWER: 91.1 / 91.3 vs 90.2 / 90.7 ms per forward of 4096 images (same box, alternating) -- the pieces
+            // then land later than the next stage's wait; the 11 % the weight stream costs is not its issue slot.
+            __builtin_amdgcn_sched_barrier(0);
+            dma_w1(kt + 1 < nk ? kt + 1 : kt, cur ^ 1, mi);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
         C1_STAMP(st_mfma)
         store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
     };
