@@ -54,6 +54,9 @@ constexpr int PLANE_B = CP * KC * 2;
 #ifndef MIRX_C1H2_MIN_WG
 #define MIRX_C1H2_MIN_WG 256        // two-tile workgroups only when the launch has at least this many of them (one per CU; 512: -0.3 %)
 #endif
+#ifndef MIRX_C1H2_HALVES
+#define MIRX_C1H2_HALVES 1          // 2: the eight-wave arm (k_conv1x1_h2's HV) on y-terms launches of at least one such workgroup per CU
+#endif
 #ifndef MIRX_C1H2_NPT
 #define MIRX_C1H2_NPT 2             // pixel tiles per workgroup on large launches (1: the A/B arm)
 #endif
@@ -91,8 +94,12 @@ __device__ __forceinline__ void pair_exchange(const u32x4 &p, const u32x4 &q, u3
     b = u32x4{b0, b1, b2, b3};
 }
 
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED>
-__global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+// HV = 2 (the A/B arm -DMIRX_C1H2_HALVES=2, y-terms layers with two pixel tiles only): ONE workgroup of eight waves takes the
+// pixels of two of the workgroups above -- waves 0-3 one half, waves 4-7 the other, each exactly as before -- against one
+// staged copy of the weights: half the L2 -> LDS weight stream per pixel (the stream costs 11 % of the forward),
+// for one barrier shared by eight waves instead of two independent workgroups per CU.
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED, int HV = 1>
+__global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w2,
@@ -104,16 +111,21 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                                                        float *__restrict__ y_inv_out, int64_t xps, int64_t yps) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     constexpr int KIMG = 8;                        // images a workgroup's pixels may span with a table row each (else: multiply)
-    __shared__ float sBias[CM], sOsc[KIMG][CM];
+    __shared__ float sBias[CM], sOscH[HV][KIMG][CM];
     // YTERMS with a table: the image's output scale 2^t is folded into BOTH constants of the epilogue's multiply-add (a power of
     // two: fma(a, s 2^t, b 2^t) = 2^t fma(a, s, b) exactly), which takes one multiply per value out of the epilogue
     constexpr bool YFOLD = YTERMS && TABLED;
-    __shared__ float sBiasY[YFOLD ? KIMG : 1][CM];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ float sBiasYH[HV][YFOLD ? KIMG : 1][CM];
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int half_wg = HV == 2 ? wave_all >> 2 : 0, wave = wave_all & 3;       // which half of the workgroup, wave inside it
+    const int tid = threadIdx.x & 255;                                         // thread inside its half
+    float (*sOsc)[CM] = sOscH[half_wg];
+    float (*sBiasY)[CM] = sBiasYH[half_wg];
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
-    constexpr int STAGE_N = 2 * PLANE_A + NPT * 2 * PLANE_B;       // bytes of one LDS stage
-    const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT);
+    constexpr int STAGE_N = 2 * PLANE_A + HV * NPT * 2 * PLANE_B;  // bytes of one LDS stage
+    const int hb = half_wg * (NPT * 2 * PLANE_B);                   // this half's activation planes inside a stage
+    const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT * HV) + half_wg * (CP * NPT);
     const int co0 = blockIdx.y * CM;
     const int nk = cin / KC;
 
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 
     // ---- staging assignments ------------------------------------------------------------------------
     // B: thread -> pixel (t & 127), channel group kg = t >> 7 (wave-uniform): channels 8 kg .. 8 kg + 7
-    const int b_px = threadIdx.x & 127;
+    const int b_px = tid & 127;
     const int b_kg = wave >> 1;
     const int64_t in_hw = xps;                                        // channel-plane stride of x (>= hw)
     const float *xsrc[NPT];
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
 #else
     const int b_row = YTERMS ? ((b_px & ~31) | ((b_px & 15) << 1) | ((b_px >> 4) & 1)) : b_px;
 #endif
-    const int b_lds = 2 * PLANE_A + b_row * 32 + ((b_kg ^ ((b_row >> 3) & 1)) << 4);   // + tile * 2 PLANE_B + term * PLANE_B
+    const int b_lds = 2 * PLANE_A + hb + b_row * 32 + ((b_kg ^ ((b_row >> 3) & 1)) << 4);   // + tile * 2 PLANE_B + term * PLANE_B
     const int ep_px = YTERMS ? 16 * (lane & 1) + ((lane & 31) >> 1) : (lane & 31);     // this lane's pixel within its 32-block
     // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
     // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
@@ -160,7 +172,8 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         (void *)(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)), 0, nk * (2 * CM * KC * 2), 0x00020000);
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
     [[maybe_unused]] auto dma_w1 = [&](int kt, int buf, int i) {
-        const int piece = wave + 4 * i;
+        if (HV == 2 && i) return;                                  // eight waves: one piece each
+        const int piece = HV == 2 ? wave_all : wave + 4 * i;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE_N + piece * 1024), 16, w_voff,
                                                  kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
     };
@@ -245,10 +258,10 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
         const int ra_ = wm * 64 + t * 32 + (lane & 31);
         fa[t] = ra_ * 32 + ((kg ^ ((ra_ >> 3) & 1)) << 4);
         const int rb_ = wn * 64 + t * 32 + (lane & 31);
-        fb[t] = 2 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
+        fb[t] = 2 * PLANE_A + hb + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
     }
 
-    const unsigned img_first = (unsigned)p0 / (unsigned)hw;
+    const unsigned img_first = (unsigned)(p0 < total ? p0 : total - 1) / (unsigned)hw;   // (HV = 2: the last workgroup's second half may hold no pixel)
     const unsigned p_last = (unsigned)(p0 + CP * NPT - 1 < total ? p0 + CP * NPT - 1 : total - 1);
     constexpr bool tabled = TABLED;
 
@@ -337,10 +350,11 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
     dma_w(0, 0);
     load(0, ra, sca, sha);
     load(nk > 1 ? 1 : 0, rb, scb, shb);
-    if (threadIdx.x < CM) {
-        sBias[threadIdx.x] = bias ? bias[co0 + threadIdx.x] : 0.f;
-        const float osc = oscale[co0 + threadIdx.x];
-        sOsc[0][threadIdx.x] = osc;
+    if (tid < CM) {
+        const float bias_v = bias ? bias[co0 + tid] : 0.f;
+        if (half_wg == 0) sBias[tid] = bias_v;
+        const float osc = oscale[co0 + tid];
+        sOsc[0][tid] = osc;
         if (tabled) {
             const unsigned nimg = p_last / (unsigned)hw - img_first + 1;
             for (unsigned k = 0; k < nimg; ++k) {
@@ -349,8 +363,8 @@ __global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const floa
                 range_scales(xb_, xs_, xi_);
                 float ys_ = 1.f, yi_;
                 if (YFOLD) range_scales(fmaf(y_ks, xb_, y_kb), ys_, yi_);
-                sOsc[k][threadIdx.x] = osc * xi_ * ys_;                 // powers of two: exact
-                if (YFOLD) sBiasY[k][threadIdx.x] = sBias[threadIdx.x] * ys_;
+                sOsc[k][tid] = osc * xi_ * ys_;                         // powers of two: exact
+                if (YFOLD) sBiasY[k][tid] = bias_v * ys_;
             }
         }
     }
@@ -550,8 +564,9 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     if (px >= ((int64_t)1 << 31) - 2 * CP) return hipErrorInvalidValue;      // the kernel indexes pixels with 32 bits
     if (yterms && px >= ((int64_t)1 << 27)) return hipErrorInvalidValue;     // ... and the 32-byte records of y (16 per pixel) too
     const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
-    const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
-    const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
+    const int hv = (MIRX_C1H2_HALVES == 2 && yterms && npt == 2 && px >= (int64_t)4 * CP * 256) ? 2 : 1;
+    const dim3 grid((unsigned)((px + CP * npt * hv - 1) / (CP * npt * hv)), (unsigned)(cout / CM));
+    const size_t lds = 2 * (size_t)(2 * PLANE_A + hv * npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
     // the oscale table has 8 rows: a workgroup's CP * npt pixels span at most (CP * npt - 1) / hw + 2 images
     const bool tabled = (CP * npt - 1) / hw + 2 <= 8;
@@ -559,23 +574,28 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     {                                                                                                      \
         if (tabled) MIRX_H2KT(P, R, T, N, true) else MIRX_H2KT(P, R, T, N, false)                          \
     }
-#define MIRX_H2KT(P, R, T, N, TB)                                                                          \
+#define MIRX_H2KT(P, R, T, N, TB) MIRX_H2KH(P, R, T, N, TB, 1)
+#define MIRX_H2KH(P, R, T, N, TB, H)                                                                       \
     {                                                                                                      \
         static bool attr_set = false;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + N * 2 * PLANE_B)); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB, H>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + H * N * 2 * PLANE_B)); \
             if (e != hipSuccess) return e;                                                                 \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB, H>), grid, dim3(256 * H), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
                            n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, xps, yps); \
     }
 #define MIRX_H2C(P, R, T)                                                                                  \
     {                                                                                                      \
         if (npt == 2) MIRX_H2K(P, R, T, 2) else MIRX_H2K(P, R, T, 1)                                        \
     }
-    if (yterms) {
+    if (yterms && hv == 2) {
+#if MIRX_C1H2_HALVES == 2
+        if (tabled) MIRX_H2KH(true, true, true, 2, true, 2) else MIRX_H2KH(true, true, true, 2, false, 2)
+#endif
+    } else if (yterms) {
         MIRX_H2C(true, true, true)
     } else if (scale) {
         if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)
@@ -584,6 +604,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     }
 #undef MIRX_H2K
 #undef MIRX_H2KT
+#undef MIRX_H2KH
 #undef MIRX_H2C
     return hipGetLastError();
 }
