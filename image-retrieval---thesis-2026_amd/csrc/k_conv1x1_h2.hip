@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
 #pragma unroll
         for (int u = 0; u < NPT; ++u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
+            for (int j = 0; j < 8; ++j) {
+#ifdef MIRX_C1H2_SC1_LOADS              // the A/B arm: agent-scope loads (sc1) pass the vector L1 by, which then holds only the weight pieces
+                r[u][j] = __hip_atomic_load(xsrc[u] + ((int64_t)kt * KC + j) * in_hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
+#endif
+            }
         if (PROLOGUE) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
