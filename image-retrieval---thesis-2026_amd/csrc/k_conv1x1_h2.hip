@@ -431,8 +431,10 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
     if (YTERMS) {
         // y as the 3x3 conv wants it: [image][group g of 16 channels][term][pixel][16] fp16, where group g = 4 wm + 2 mi +
         // (lane >> 5) holds exactly the 16 channels this lane owns in accumulator tile mi (the consumer's weights are
-        // permuted to the same channel order: mirx.model.YTERMS_CHANNEL_ORDER): a lane writes 32 contiguous bytes per term,
-        // a half-wave 1 KiB
+        // permuted to the same channel order: mirx.model.YTERMS_CHANNEL_ORDER): a pixel's record of a (group, term) is the 32
+        // bytes of ONE lane.  The lanes 2 j and 2 j + 1 (pixels j and 16 + j of the 32-block, see b_row) swap halves, so that a
+        // store instruction writes whole records: the pair writes pixel j in instruction A and pixel 16 + j in instruction B, a
+        // half-wave 512 contiguous bytes in each
         uint16_t *yt = reinterpret_cast<uint16_t *>(y);
         // the neighbour's value (lanes 2 j <-> 2 j + 1)
         auto nb = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
