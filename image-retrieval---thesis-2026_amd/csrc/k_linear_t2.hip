@@ -103,6 +103,8 @@ __device__ inline void finish4(f32x4 v, int64_t row, int col, const f32x4 &bv, c
         unsigned h0, l0, h1, l1;
         split2h_pair(v[0] * y_scale, v[1] * y_scale, h0, l0);
         split2h_pair(v[2] * y_scale, v[3] * y_scale, h1, l1);
+        // (a pair of lanes swapping halves so that each writes 16 bytes -- eight lanes a whole 128-byte line per instruction --
+        // measured 1 043 vs 1 048 img/s on DINOv2, 327 vs 328 on MedSigLIP: no gain over the two 8-byte stores, not kept)
         const u32x2 hi = {h0, h1}, lo = {l0, l1};
         char *dst = yt + row * ((int64_t)np * 4) + (col >> 5) * LINE + (col & 31) * 2;
         *reinterpret_cast<u32x2 *>(dst) = hi;
