@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                     const int col = n0 + wn * 64 + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (col >= n) continue;                     // zero-padded weight rows of the last output tile
                     float v = acc[mi][ni][r] * out_scale + (bias ? bias[col] : 0.f);
-                    if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 1) v = gelu_erf(v);
                     if (ACT == 2) v = gelu_tanh(v);
                     const int64_t idx = base + (int64_t)col * tpi;
                     if (RES) v = res[idx] + v;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void k_linear_h2(const float *__restrict__ 
                 if (row >= m) continue;
                 float v = acc[mi][ni][r] * out_scale + bv;
                 if (MIRX_LH2_EXP != 3) {
-                    if (ACT == 1) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                    if (ACT == 1) v = gelu_erf(v);
                     if (ACT == 2) v = gelu_tanh(v);
                     if (RES) v = res[row * n + col] + gv * v;
                 }

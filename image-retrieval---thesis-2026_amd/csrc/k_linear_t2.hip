@@ -65,7 +65,7 @@ __device__ inline void finish4(f32x4 v, int64_t row, int col, const f32x4 &bv, c
     for (int e = 0; e < 4; ++e) {
         float t = v[e] * out_scale + bv[e];
         if (!(MIRX_LT2_EXP & 4)) {
-            if (ACT == 1) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+            if (ACT == 1) t = gelu_erf(t);
             if (ACT == 2) t = gelu_tanh(t);
         }
         v[e] = t;

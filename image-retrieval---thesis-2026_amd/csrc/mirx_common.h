@@ -93,11 +93,21 @@ __device__ inline double lane_tree_score(const float *__restrict__ q, const floa
     acc = wave_butterfly_sum(acc);
     return METRIC == 0 ? acc : -acc;
 }
-// tanh-form GELU (transformers "gelu_pytorch_tanh", the SigLIP MLP activation): 0.5 v (1 + tanh(sqrt(2/pi) (v + 0.044715 v^3)))
+// tanh-form GELU (transformers "gelu_pytorch_tanh", the SigLIP MLP activation): 0.5 v (1 + tanh(u)), u = sqrt(2/pi) (v + 0.044715 v^3).
+// 1 + tanh(u) = 2 / (1 + e^(-2u)) exactly, so the value is v / (1 + 2^(v (K1 + K2 v^2))) with K1 = -2 sqrt(2/pi) log2(e), K2 =
+// 0.044715 K1: one v_exp_f32 and one v_rcp_f32 instead of tanhf's ~25 instructions (the Linear epilogues are VALU-bound on their
+// activation).  Against float64 over [-12, 12]: 7.4e-7 absolute, 1.3e-6 relative where |value| > 1e-3 -- the tanhf form measures
+// 6.7e-7 and 5e-5 (it cancels in 1 + tanh for negative arguments).
 __device__ inline float gelu_tanh(float v) {
-    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    return 0.5f * v * (1.f + tanhf(u));
+    const float a = fmaf(v * v, -0.10294324159622192f, -2.302208185195923f);
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * a));
 }
+
+// erf-form GELU (torch.nn.GELU()).  A branch-free erf (two fitted polynomials evaluated for every value so that neighbours pair
+// into packed fp32 instructions, tools/fit_gelu.py) was built and measured: DINOv2 1 031 -> 1 032 img/s, ConvNeXtV2 2 049 ->
+// 2 021 -- ocml's erff mostly runs ONE of its branches per wave (|z| < 1 for most activations), which is cheaper than both
+// polynomials at half price.  Kept: erff.
+__device__ inline float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
 // ---- value ranges that travel with activations (two-fp16-term kernels) ---------------------------------
 // PER IMAGE: a buffer's range is one fp32 per image (a "range row" [n], zeroed once per forward).  A producer folds the
