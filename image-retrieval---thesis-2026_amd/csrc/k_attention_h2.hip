@@ -13,6 +13,11 @@ namespace mirx {
 
 namespace {
 
+// 2^x as the bare v_exp_f32.  exp2f() wraps the instruction in a compare, two selects, an add and a multiply so that results below
+// 2^-126 come out as denormals; a softmax weight that small changes neither the running sum (>= 1) nor its bf16 terms, and the
+// wrapper was 4 of every 6 VALU instructions of the softmax.
+__device__ inline float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+
 typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;   // (fp16 here)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -211,11 +216,11 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));            // the other 16 keys of the same query
         const float m_new = fmaxf(m_run, mt);              // finite: every tile holds at least one valid key
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = exp2f(sacc[r] - m_new);
+            sacc[r] = exp2_raw(sacc[r] - m_new);
             psum += sacc[r];
         }
         l_run = l_run * alpha + psum;
@@ -432,11 +437,11 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = exp2f(sacc[r] - m_new);
+            sacc[r] = exp2_raw(sacc[r] - m_new);
             psum += sacc[r];
         }
         l_run = l_run * alpha + psum;
