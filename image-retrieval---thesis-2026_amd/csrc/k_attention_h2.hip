@@ -202,33 +202,35 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + K_PLANE);
             MIRX_MFMA3(sacc, ah, al, qh[ks], ql[ks])
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] *= s_inv;      // exact: a power of two
+        // (the scores stay unscaled: s_inv, a power of two, goes into the exponent's multiply-add below -- the same bits)
 
         // ---- online softmax over this lane's 16 keys (base 2) -----------------------------------------------------
         const int key0 = kt * KT + 4 * half;
+        const bool tail_tile = (kt + 1) * KT > n;          // wave-uniform: only the last tile can hold keys beyond n
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + 8 * (r >> 2) + (r & 3);
-            if (key >= n) sacc[r] = -INFINITY;
+            if (tail_tile && key >= n) sacc[r] = -INFINITY;
             mt = fmaxf(mt, sacc[r]);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));            // the other 16 keys of the same query
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * s_inv;    // the other 16 keys of the same query; max commutes with the positive scale
         const float m_new = fmaxf(m_run, mt);              // finite: every tile holds at least one valid key
         const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = exp2_raw(sacc[r] - m_new);
+            sacc[r] = exp2_raw(fmaf(sacc[r], s_inv, -m_new));
             psum += sacc[r];
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                       // wave-uniform: once the running maxima have settled there is nothing to rescale
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T: step s contracts the keys kappa(8 s + i, half) = this lane's sacc[8 s + i] -------------
 #pragma unroll
@@ -424,32 +426,34 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + KPL);
             MIRX_MFMA3(sacc, ah, al, qh[ks], ql[ks])
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] *= s_inv;      // exact: a power of two
+        // (the scores stay unscaled: s_inv, a power of two, goes into the exponent's multiply-add below -- the same bits)
 
         const int key0 = kt * KT + 4 * half;
+        const bool tail_tile = (kt + 1) * KT > n;          // wave-uniform: only the last tile can hold keys beyond n
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + 8 * (r >> 2) + (r & 3);
-            if (key >= n) sacc[r] = -INFINITY;
+            if (tail_tile && key >= n) sacc[r] = -INFINITY;
             mt = fmaxf(mt, sacc[r]);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * s_inv;
         const float m_new = fmaxf(m_run, mt);
         const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = exp2_raw(sacc[r] - m_new);
+            sacc[r] = exp2_raw(fmaf(sacc[r], s_inv, -m_new));
             psum += sacc[r];
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
