@@ -123,3 +123,27 @@ def test_channels_last_patch_rows_reproduce_the_stride2_convolution():
     assert float((got - want).abs().max()) < 1e-5
     plain = mm._ConvAsLinear(conv).refresh()                                                  # (c, ky, kx): the NCHW patch gather's order
     assert not torch.equal(plain.weight, pl.weight)
+
+
+def test_tanh_gelu_sigmoid_form_is_as_accurate_as_the_tanh_form():
+    """csrc/mirx_common.h:gelu_tanh computes v / (1 + 2^(v (K1 + K2 v^2))) -- the identity 1 + tanh(u) = 2 / (1 + e^(-2u)) -- with
+    one v_exp_f32 and one v_rcp_f32.  Emulated in float32 with numpy: within 1e-6 (absolute) of the float64 value of the
+    reference's activation (transformers "gelu_pytorch_tanh") and at least as accurate relatively as the tanh form itself."""
+    import numpy as np
+    f32 = np.float32
+    t = np.linspace(-12.0, 12.0, 240001)
+    v = t.astype(f32)
+    k1 = f32(-2.302208185195923)                 # -2 sqrt(2/pi) log2(e): the constants of the kernel
+    k2 = f32(-0.10294324159622192)               # 0.044715 K1
+    assert abs(float(k1) + 2 * 0.7978845608028654 * 1.4426950408889634) < 1e-7
+    assert abs(float(k2) - 0.044715 * float(k1)) < 1e-8
+    with np.errstate(over="ignore"):
+        e = np.exp2((v * ((v * v).astype(f32) * k2 + k1).astype(f32)).astype(f32)).astype(f32)
+    got = (v * (f32(1) / (f32(1) + e).astype(f32)).astype(f32)).astype(f32)
+    ref = 0.5 * t * (1 + np.tanh(0.7978845608028654 * (t + 0.044715 * t ** 3)))
+    assert float(np.abs(got - ref).max()) < 1e-6
+    u = (f32(0.7978845608028654) * (v + f32(0.044715) * v * v * v)).astype(f32)
+    tanh_form = (f32(0.5) * v * (f32(1) + np.tanh(u.astype(np.float64)).astype(f32))).astype(f32)
+    big = np.abs(ref) > 1e-3
+    rel = lambda x: float((np.abs(x - ref)[big] / np.abs(ref[big])).max())
+    assert rel(got) < 2e-6 and rel(got) <= rel(tanh_form)
