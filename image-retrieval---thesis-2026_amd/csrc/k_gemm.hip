@@ -80,6 +80,9 @@ __device__ inline void stage_tile(char *lds_tile, __amdgpu_buffer_rsrc_t rsrc, i
 // query group (4 tiles) > phase > tile in group and dealt to workgroups so that unit U runs on XCD
 // label U / (grid/8): the 32 workgroups of an XCD label then share 4 query tiles (2 MiB, L2
 // resident) and stream 8 gallery tiles at a time.  Speed only -- any assignment is correct.
+#ifndef MIRX_PLAN_GROUP
+#define MIRX_PLAN_GROUP 4      // query tiles that share a stream of gallery tiles (speed only; A/B arm of tools/gemm_ab.py)
+#endif
 struct Plan {
     int64_t ngt;     // gallery tiles
     int nqt;         // query tiles
@@ -87,15 +90,16 @@ struct Plan {
     int grid;        // workgroups launched (multiple of 8)
     __host__ __device__ int units() const { return nqt * nph; }
     __host__ __device__ void unit(int u, int &qt, int &ph) const {
-        const int full_groups = nqt / 4, per_group = 4 * nph;
+        constexpr int G = MIRX_PLAN_GROUP;
+        const int full_groups = nqt / G, per_group = G * nph;
         if (u < full_groups * per_group) {
             const int g = u / per_group, l = u % per_group;
-            ph = l >> 2;
-            qt = g * 4 + (l & 3);
+            ph = l / G;
+            qt = g * G + (l % G);
         } else {
-            const int l = u - full_groups * per_group, gsz = nqt - 4 * full_groups;
+            const int l = u - full_groups * per_group, gsz = nqt - G * full_groups;
             ph = l / gsz;
-            qt = full_groups * 4 + l % gsz;
+            qt = full_groups * G + l % gsz;
         }
     }
 };
@@ -394,6 +398,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
 // ================================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+__device__ inline float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ inline float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int MODE, bool L2>
 __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     constexpr int BN = 256;
@@ -435,6 +450,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     const int pstride_a = 64 * rs * ld_bytes;
     const int pstride_b = 64 * ld_bytes;
     auto make_rsrc_a = [&](int64_t gt_) {
+#ifdef MIRX_EXP_SAMEA   // diagnostic (results wrong): every gallery tile is the workgroup's first one, i.e. L2-resident
+        gt_ = ph;
+#endif
         return __builtin_amdgcn_make_buffer_rsrc((void *)(A.g16 + gt_ * BM * A.row_stride * A.dimp), 0,
                                                  BM * rs * ld_bytes, 0x00020000);
     };
@@ -454,14 +472,74 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // thresholds of this workgroup's 256 queries: LDS, read back per gallery tile by the epilogue
     float *ltau = reinterpret_cast<float *>(lcnt + BN * WARPS_M);
     if (MODE == 0 && threadIdx.x < BN) ltau[threadIdx.x] = A.tau[q_row0 + threadIdx.x];
-    const int region = ph * WARPS_M + wm;
 
     f32x4 acc[M_REP][N_REP];
 
+    // FUSE (cosine filter): the threshold test of gallery tile t runs INSIDE the first K-slice of tile t + 1 -- right
+    // before the MFMA pair that overwrites an accumulator tile pair, its 8 values are reduced (4 VALU), compared
+    // with the two thresholds and, rarely, handed to emit_tile() -- so the matrix pipe does not idle for the
+    // ~4 000 cycles per gallery tile that the stand-alone epilogue took while all 8 waves ran it together.
+    // The last gallery tile of a workgroup (and every tile of the L2 / group-max kernels) uses epilogue().
+#ifdef MIRX_GEMM_NOFUSE
+    constexpr bool FUSE = false;
+#else
+    constexpr bool FUSE = MODE == 0 && !L2;
+#endif
+
+    // Candidate path of one PAIR of accumulator tiles (row tile mi, query tiles n0 and n0 + 1): about two of a wave's
+    // 2 048 scores pass per gallery tile, so this is cold code -- kept small (ONE copy of the push per call site: a
+    // wave-uniform loop takes every lane's passing values one at a time) because it is inlined at 16 + 16 places.
+    // No global atomics: the region (query, this workgroup's phase, this wave row) belongs to this wave alone and
+    // its fill count lives in LDS; the four lanes that share a query (lane & 15) claim slots with one LDS atomic each
+    // (a plain load / store of the shared counter would be a data race across lanes).  Rows beyond the region's
+    // slots go to the query's overflow list.  Everything is re-derived from an opaque copy of the lane id so that
+    // none of it (64-bit columns, pointers) is hoisted into the K loop's live registers -- the loop has none to spare.
+    auto emit_pair = [&](int64_t gt_, int mi, int n0, const f32x4 a0, const f32x4 a1, float t0, float t1) {
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int quad = el >> 4, col = el & 15;
+        unsigned pm = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pm |= (a0[r] > t0 ? 1u : 0u) << r;
+            pm |= (a1[r] > t1 ? 1u : 0u) << (4 + r);
+        }
+        const int64_t row0 = gt_ * BM + wm * WM_ROWS + mi * 16 + 4 * quad;
+        while (__any(pm != 0)) {
+            if (pm != 0) {
+                const int j = __builtin_ctz(pm);
+                pm &= pm - 1;
+                float v = a0[0];
+                v = j == 1 ? a0[1] : v;
+                v = j == 2 ? a0[2] : v;
+                v = j == 3 ? a0[3] : v;
+                v = j == 4 ? a1[0] : v;
+                v = j == 5 ? a1[1] : v;
+                v = j == 6 ? a1[2] : v;
+                v = j == 7 ? a1[3] : v;
+                const int64_t grow = (row0 + (j & 3)) * A.row_stride;
+                if (grow < A.n_rows) {                 // rows beyond the gallery exist in its last (partial) tile
+                    const int qi = wn * 64 + (n0 + (j >> 2)) * 16 + col;
+                    const int64_t qc = q_row0 + qi;
+                    const int c = atomicAdd(&lcnt[qi * WARPS_M + wm], 1);
+                    Cand cd;
+                    cd.s = v;
+                    cd.row = (int32_t)grow;
+                    if (c < A.slots) {
+                        A.cand[(qc * A.regions + (ph * WARPS_M + wm)) * A.slots + c] = cd;
+                    } else {
+                        const int p = atomicAdd(&A.ovf_cnt[qc], 1);
+                        if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
+                    }
+                }
+            }
+        }
+    };
+    // largest of an accumulator tile's four values in two instructions (fmaxf() would first canonicalise each
+    // operand with a v_max_f32 x, x: four more instructions per tile in the fused check's issue budget)
+#define MIRX_TILEMAX(T) vmax2(vmax3((T)[0], (T)[1], (T)[2]), (T)[3])
+
     auto epilogue = [&](int64_t gt_) {
-        // Everything the epilogue needs besides tau[] is re-derived here from an opaque copy of the lane
-        // id, so that none of it (64-bit columns, pointers, ballot masks) is hoisted into the K loop's
-        // live registers -- the loop has none to spare.
         int el = lane;
         asm volatile("" : "+v"(el));
         const int quad = el >> 4, col = el & 15;
@@ -483,54 +561,36 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // rows beyond the gallery exist only in its last (partial) tile: test them only there
-        const bool partial = (tile_row0 + WM_ROWS) * A.row_stride > A.n_rows;
+        if (MODE == 1) {
 #pragma unroll
-        for (int ni = 0; ni < N_REP; ++ni) {
-            // maximum per row tile first: the candidate path below then looks only inside row tiles that
-            // hold a passing score (about two scores per wave and gallery tile pass, out of 2048)
-            float mrow[M_REP];
-            float mx = -INFINITY;
+            for (int ni = 0; ni < N_REP; ++ni) {
+                float mx = -INFINITY;
 #pragma unroll
-            for (int mi = 0; mi < M_REP; ++mi) {
-                mrow[mi] = fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3]));
-                mx = fmaxf(mx, mrow[mi]);
-            }
-            if (MODE == 1) {
+                for (int mi = 0; mi < M_REP; ++mi) mx = fmaxf(mx, MIRX_TILEMAX(acc[mi][ni]));
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 if (quad == 0)
                     A.groupmax[(q_row0 + wn * 64 + ni * 16 + col) * A.ngroups + gt_ * WARPS_M + wm] = mx;
-            } else if (__any(mx > tau[ni])) {
-                // Candidate path.  No global atomics: the region (query, this workgroup's phase, this wave
-                // row) belongs to this wave alone and its fill count lives in LDS.  The four lanes that share
-                // a query (lane & 15) claim slots with one LDS atomic each.  Rows beyond the region's slots go to the query's overflow list.
-                const int64_t qc = q_row0 + wn * 64 + ni * 16 + col;
-                const int cidx = (wn * 64 + ni * 16 + col) * WARPS_M + wm;
-                Cand *dst = A.cand + (qc * A.regions + region) * A.slots;
+            }
+        } else {
+#pragma unroll
+            for (int n0 = 0; n0 < N_REP; n0 += 2) {
+                // maxima per row tile first: the candidate path then looks only inside row tiles that
+                // hold a passing score (about two scores per wave and gallery tile pass, out of 2048)
+                float mr0[M_REP], mr1[M_REP];
+                float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
                 for (int mi = 0; mi < M_REP; ++mi) {
-                    if (!__any(mrow[mi] > tau[ni])) continue;
+                    mr0[mi] = MIRX_TILEMAX(acc[mi][n0]);
+                    mr1[mi] = MIRX_TILEMAX(acc[mi][n0 + 1]);
+                    mx0 = fmaxf(mx0, mr0[mi]);
+                    mx1 = fmaxf(mx1, mr1[mi]);
+                }
+                if (__builtin_expect(__any((mx0 > tau[n0]) | (mx1 > tau[n0 + 1])), 0)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[mi][ni][r];
-                        const int64_t grow = (tile_row0 + mi * 16 + 4 * quad + r) * A.row_stride;
-                        const bool pass = v > tau[ni] && (!partial || grow < A.n_rows);
-                        if (pass) {
-                            // one LDS atomic per passing score: the four lanes that share a query get distinct slots
-                            // (a plain load / store of the shared counter would be a data race across lanes)
-                            const int c = atomicAdd(&lcnt[cidx], 1);
-                            Cand cd;
-                            cd.s = v;
-                            cd.row = (int32_t)grow;
-                            if (c < A.slots) {
-                                dst[c] = cd;
-                            } else {
-                                const int p = atomicAdd(&A.ovf_cnt[qc], 1);
-                                if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
-                            }
-                        }
-                    }
+                    for (int mi = 0; mi < M_REP; ++mi)
+                        if (__any((mr0[mi] > tau[n0]) | (mr1[mi] > tau[n0 + 1])))
+                            emit_pair(gt_, mi, n0, acc[mi][n0], acc[mi][n0 + 1], tau[n0], tau[n0 + 1]);
                 }
             }
         }
@@ -550,7 +610,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // Z = 1: the first slice of a gallery tile starts its 32 accumulator tiles from the constant 0 (no
     // 128 v_mov per tile)
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // with FUSE, Z = 1 also means: test the previous gallery tile's values of the two accumulator tiles first
+    float ftau[N_REP] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t gt_prev = 0;
+#define MIRX_CHECK2(MI, N0)                                                                                      \
+    {                                                                                                            \
+        const float m0_ = MIRX_TILEMAX(acc[MI][N0]);                                                             \
+        const float m1_ = MIRX_TILEMAX(acc[MI][(N0) + 1]);                                                       \
+        if (__builtin_expect(__any((m0_ > ftau[N0]) | (m1_ > ftau[(N0) + 1])), 0))                               \
+            emit_pair(gt_prev, MI, N0, acc[MI][N0], acc[MI][(N0) + 1], ftau[N0], ftau[(N0) + 1]);                \
+    }
 #define MIRX_MFMA2Z(MI, N0, Z)                                                                         \
+    if constexpr ((Z) && FUSE) MIRX_CHECK2(MI, N0)                                                     \
     acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], (Z) ? zero4 : acc[MI][N0], 0, 0, 0); \
     acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], (Z) ? zero4 : acc[MI][N0 + 1], 0, 0, 0);
 #define MIRX_MFMA2(MI, N0) MIRX_MFMA2Z(MI, N0, 0)
@@ -591,14 +662,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #define MIRX_SLOT_A(G, P)
 #define MIRX_SLOT_B(G, P)
 #else
-#define MIRX_SLOT_A(G, P)                                                           \
+#define MIRX_SLOT_A_(G, P)                                                          \
     if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(dma_rsrc, LDS_PTR(dma_a + (P) * 8192), 16, voff_a, \
                                                  dma_koff + (P) * pstride_a, 0, MIRX_GEMM_A_AUX);
-#define MIRX_SLOT_B(G, P)                                                           \
+#define MIRX_SLOT_B_(G, P)                                                          \
     if (MIRX_SLOT_COND(G))                                                          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(dma_b + (P) * 8192), 16, voff_b, \
                                                  dma_koff + (P) * pstride_b, 0, 0);
+#ifdef MIRX_EXP_NOA         // diagnostic (results wrong): no gallery DMA inside the loop
+#define MIRX_SLOT_A(G, P)
+#else
+#define MIRX_SLOT_A(G, P) MIRX_SLOT_A_(G, P)
+#endif
+#ifdef MIRX_EXP_NOB         // diagnostic (results wrong): no query DMA inside the loop
+#define MIRX_SLOT_B(G, P)
+#else
+#define MIRX_SLOT_B(G, P) MIRX_SLOT_B_(G, P)
+#endif
 #endif
 
     // H1 of a slice: query tiles 0,1 of every row tile; B fragments 2,3 of the same slice are read early
@@ -716,6 +797,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // (bench: 5.75 -> 5.54 ms per 4096-query launch).
     if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 
+    if constexpr (FUSE) {
+        // nothing of "the tile before the first" passes a threshold
+        const f32x4 ninf4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int mi = 0; mi < M_REP; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < N_REP; ++ni) acc[mi][ni] = ninf4;
+    }
+
     for (;;) {
         const int64_t gt_nx = gt + plan.nph;
         const bool have_next = gt_nx < plan.ngt;
@@ -724,6 +814,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #ifdef MIRX_EXP_CYCLES
         const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int ni = 0; ni < N_REP; ++ni) ftau[ni] = ltau[wn * 64 + ni * 16 + (lane & 15)];
+        }
         MIRX_KTILE(0, 1)                               // the first slice initialises the accumulators
 #pragma unroll 1
         for (int kt = 1; kt < nk; ++kt) {
@@ -737,15 +831,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #ifdef MIRX_EXP_CYCLES
         const unsigned long long ep0 = __builtin_amdgcn_s_memtime();
 #endif
-        epilogue(gt);
+        if constexpr (!FUSE) epilogue(gt);
 #ifdef MIRX_EXP_CYCLES
         ep_sum += __builtin_amdgcn_s_memtime() - ep0;
         ep_n += 1;
 #endif
         if (!have_next) break;
+        gt_prev = gt;
         gt = gt_nx;
         rsrc_a = rsrc_a_nx;
     }
+    if constexpr (FUSE) epilogue(gt);                  // the last gallery tile of this workgroup
 #ifdef MIRX_EXP_CYCLES
     if (lane == 0 && (blockIdx.x % 61) == 0 && cy_n > 1000 && (wave == 0 || wave == 4))
         printf("wg %d wave %d: %.0f cycles per K-tile in the K loop (%llu K-tiles); epilogue %.0f cycles per gallery tile; kernel %.0f cycles per K-tile\n",
@@ -769,6 +865,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #undef MIRX_H2_ROW
 #undef MIRX_MFMA2
 #undef MIRX_MFMA2Z
+#undef MIRX_CHECK2
+#undef MIRX_TILEMAX
 #undef MIRX_H2_ROWZ
 #undef MIRX_LDA
 #undef MIRX_LDB
