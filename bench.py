@@ -96,30 +96,6 @@ def build_shard(index, lo, hi, dim, device, chunk=1 << 16):
         index.add(rows[a - c * chunk: b - c * chunk], torch.arange(a, b, device=device))
 
 
-def gemm_traffic_from_profile(args, world, q_local):
-    """HBM-side bytes per launch of the filter GEMM from the committed PMC passes
-    (profiles/r01_gemm_pmc.csv: separate FETCH_SIZE / WRITE_SIZE runs of tools/bench_search.py --q 4096;
-    FETCH_SIZE is in KB and counts half the bytes of wide coalesced loads on gfx950).  Only valid for
-    the configuration those passes ran on; otherwise null."""
-    if not (world == 1 and q_local == 4096 and args.gallery == 1_000_000 and args.dim == 1024):
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc.csv")
-    if not os.path.exists(path):
-        return None
-    import csv
-    fetch, write = [], []
-    with open(path) as fh:
-        for r in csv.DictReader(fh):
-            if "k_gemm16<0, false>" in r["Kernel_Name"]:
-                if r["Counter_Name"] == "FETCH_SIZE":
-                    fetch.append(float(r["Counter_Value"]))
-                elif r["Counter_Name"] == "WRITE_SIZE":
-                    write.append(float(r["Counter_Value"]))
-    if not fetch or not write:
-        return None
-    return (2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0
-
-
 def cpu_baseline(index, model, args, dev):
     """Reference CPU path on a bounded sample: embed 64 images (B=64, test.py:1513) + cdist/topk of 32 queries."""
     from oracle import densenet as OD
@@ -151,7 +127,7 @@ def cpu_baseline(index, model, args, dev):
 def profile_traffic(name, key):
     """Fabric-side bytes from the committed PMC summary of the newest round that has one (tools/pmc_traffic.py: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2 on gfx950).  -> (value, file name) or (None, None)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             with open(path) as fh:
@@ -198,6 +174,28 @@ def timed_images_per_s(model, x, iters, warmup=2):
     return x.shape[0] * iters / (time.perf_counter() - t0)
 
 
+def densenet_batch_curve(model, args, dev, batches=(1, 8, 32, 64, 256, 1024)):
+    """The reference's loops run at B = 64 (test.py:1513), 32 (ingest_embeddings.py:467), 1 (milvus_retrieval.py:53-66) and
+    ~53 per metric call (the XAI loop): images/s and ms per forward at those batch sizes, ONE stream, device-resident fp32
+    images.  The step itself embeds 4096 images on two streams (`value`)."""
+    out = []
+    x = synthetic_images(max(batches), args.image_size, 4242, dev)
+    with torch.no_grad():
+        for b in batches:
+            xb = x[:b].contiguous()
+            for _ in range(3):
+                model(xb)
+            torch.cuda.synchronize(dev)
+            iters = max(3, min(200, int(2000 / max(b, 8))))
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                model(xb)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / iters
+            out.append({"batch": b, "ms_per_forward": dt * 1e3, "images_per_s": b / dt})
+    return out
+
+
 def overlap_ab(model, index, pool, args, dev, steps=6):
     """search of step i beside the embed of step i + 1 (mirx_index_search_begin / _end on its own stream, two embedding
     buffers) against the plain sequence, same box, same run: queries/s of both.  N = 1 only."""
@@ -206,6 +204,7 @@ def overlap_ab(model, index, pool, args, dev, steps=6):
     side = [torch.cuda.Stream(device=dev) for _ in range(2)]
     sstream = torch.cuda.Stream(device=dev)
     cur = torch.cuda.current_stream(dev)
+    done = [None, None]                  # event on the search stream: every pass that reads embs[i] has been enqueued and run
 
     def embed(dst):
         part = q // 2
@@ -223,6 +222,8 @@ def overlap_ab(model, index, pool, args, dev, steps=6):
         with torch.no_grad():
             for i in range(steps):
                 buf = embs[i % 2]
+                if overlap and done[i % 2] is not None:
+                    cur.wait_event(done[i % 2])          # search_end(i - 2)'s follow-up passes read this buffer
                 embed(buf)
                 if not overlap:
                     index.search(buf, args.k, return_f64=True)
@@ -231,6 +232,8 @@ def overlap_ab(model, index, pool, args, dev, steps=6):
                 if pending is not None:
                     with torch.cuda.stream(sstream):
                         index.search_end(pending, return_f64=True)
+                        done[(i - 1) % 2] = torch.cuda.Event()
+                        done[(i - 1) % 2].record(sstream)
                 with torch.cuda.stream(sstream):
                     pending = index.search_begin(buf, args.k)
             if pending is not None:
@@ -424,6 +427,29 @@ def self_launch(args):
     return rc
 
 
+def rank_provenance(world, rank, local_rank, rehearse, device_name):
+    """What proves, on the line itself, which backend carried the collectives and which device every rank drove:
+    gathered from all ranks (all_gather_object runs on the default group's backend)."""
+    import socket
+    import torch.distributed as dist
+    mine = {"rank": rank, "local_rank": local_rank, "device": device_name, "host": socket.gethostname(), "pid": os.getpid(),
+            "visible_gpus": torch.cuda.device_count()}
+    if world == 1:
+        return {"collective_backend": None, "rehearsal": False, "ranks": [mine]}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    return {"collective_backend": dist.get_backend(), "rehearsal": bool(rehearse), "ranks": allr}
+
+
+def refuse_rehearsal_on_a_multi_gpu_node(args):
+    """MIRX_BENCH_REHEARSE=1 (all ranks on cuda:0, collectives over gloo) is a one-GPU development aid.  On a node with more
+    than one visible GPU a --gpus N > 1 run with it set would print a line that LOOKS like a scaling point: refuse."""
+    if os.environ.get("MIRX_BENCH_REHEARSE") == "1" and args.gpus > 1 and torch.cuda.device_count() > 1:
+        print("bench.py: MIRX_BENCH_REHEARSE=1 with --gpus > 1 on a node with more than one visible GPU: refusing to "
+              "produce a rehearsal line where a real RCCL run is possible", file=sys.stderr)
+        sys.exit(4)
+
+
 def launch_selftest(world, rank):
     """--selftest-launch: what a rank does instead of the GPU bench when only the launch path is under test (CPU
     container): gloo rendezvous, one all-reduce, rank 0 prints a line of the contract's shape."""
@@ -435,9 +461,10 @@ def launch_selftest(world, rank):
     t = torch.ones(1, dtype=torch.float64) * (rank + 1)
     if world > 1:
         dist.all_reduce(t)
+    prov = rank_provenance(world, rank, int(os.environ.get("LOCAL_RANK", "0")), False, "cpu (launch selftest)")
     if rank == 0:
         print(json.dumps({"metric": "launch selftest", "value": float(t.item()), "unit": "sum of ranks + 1", "n_gpus": world,
-                          "launch_selftest": True}), flush=True)
+                          "launch_selftest": True, **prov}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -445,6 +472,9 @@ def launch_selftest(world, rank):
 
 def main():
     args = parse()
+    if args.selftest_launch and os.environ.get("MIRX_BENCH_SELFTEST_VISIBLE_GPUS"):   # test hook: pretend the node shows that many GPUs
+        torch.cuda.device_count = lambda: int(os.environ["MIRX_BENCH_SELFTEST_VISIBLE_GPUS"])
+    refuse_rehearsal_on_a_multi_gpu_node(args)       # before any rank is started (device_count() does not initialise the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -577,14 +607,16 @@ def main():
 
     total_q = world * q_local * args.steps
     stats = index.last_stats()
+    prov = rank_provenance(world, rank, local_rank, rehearse, torch.cuda.get_device_name(dev))
     embed_roof = None
     if rank == 0 and not args.search_only:
         # calibration pass OUTSIDE the timed region: HIP events around every launch of the embed stage's dominant
         # hand-written kernel family (the fused 1x1 convolutions of the 58 dense layers and 3 transitions)
+        # (in the configuration the timed steps run: one micro-batch split over the embed streams)
         model.conv1x1_timer = []
-        xcal = pool[0][:min(args.embed_batch, 2048)]
+        xcal = pool[0]
         with torch.no_grad():
-            model(xcal)
+            embed_all() if nmb == 1 else model(xcal)
         torch.cuda.synchronize(dev)
         fams = {}
         for a, b, f, nb, kind in model.conv1x1_timer:
@@ -604,7 +636,7 @@ def main():
             embed_roof = {"bound": "hbm",
                           "kernel": ("mirx::k_conv1x1_h2 (fused BN+ReLU+1x1 conv+BN+ReLU, two fp16 MFMA terms, fp32-grade), "
                                      if kind == "conv1x1" else "mirx::k_dense_fused (one-launch dense layer, bottleneck in LDS), ")
-                                    + f"{nl} launches of one {b}-image forward",
+                                    + f"{nl} launches of one {b}-image forward on {len(side) if side and nmb == 1 else 1} stream(s)",
                           "dtype": "f32 (2 x fp16 terms)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                           "algorithmic_bytes_per_forward": nbytes, "ms_per_forward": ms,
                           "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
@@ -619,6 +651,9 @@ def main():
             "value": total_q / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
+            "collective_backend": prov["collective_backend"],       # "nccl" (= RCCL) for N > 1; null for one GPU
+            "rehearsal": prov["rehearsal"],
+            "ranks": prov["ranks"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -648,7 +683,7 @@ def main():
             line["roofline_embed"] = embed_roof
         if world == 1 and q_local == 4096 and args.gallery == 1_000_000 and args.dim == 1024:
             tr, tr_file = profile_traffic("gemm_1Mx1024_q4096", "bytes_per_launch")
-            line["roofline"]["traffic"] = tr or gemm_traffic_from_profile(args, world, q_local)
+            line["roofline"]["traffic"] = tr
             line["roofline"]["traffic_profile"] = tr_file
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(index, model, args, dev)
@@ -656,6 +691,7 @@ def main():
             ab = overlap_ab(model, index, pool, args, dev) if args.embed_batch % 2 == 0 else None
             hri = host_resident_inputs(model, index, args, dev) if args.embed_batch % 2 == 0 and args.image_size == 224 else None
             rsq = retriever_single_query(model, args, dev) if args.dim == 1024 else None
+            curve = densenet_batch_curve(model, args, dev) if args.image_size == 224 else None
             del model, index, searcher, pool
             torch.cuda.empty_cache()
             line["extras"] = extras(args, dev)
@@ -665,6 +701,8 @@ def main():
                 line["extras"]["host_resident_inputs"] = hri
             if rsq is not None:
                 line["extras"]["retriever_single_query"] = rsq
+            if curve is not None:
+                line["extras"]["densenet_batch_curve"] = curve
             line["roofline"]["other_dims"] = {k: {kk: v[kk] for kk in ("gemm_ms", "gemm_tflops", "gemm_frac_of_bf16_peak")}
                                               for k, v in line["extras"].items() if k.startswith("search_only_")}
         print(json.dumps(line), flush=True)

@@ -17,6 +17,8 @@ OPT_TIERS = 1
 OPT_SAMPLE_RANK = 2
 OPT_FORCE_TAU = 3
 OPT_PROFILE = 4
+TUNE_CONV1X1_SMALL_MAX_WG = 1      # mirx_set_tuning keys
+TUNE_CONV3X3_SMALL_MAX_WG = 2
 STAGES = ("prep", "sample", "gemm", "finalize", "exact")
 FORCE_TAU_OFF = 0x7FC00000
 
@@ -39,6 +41,7 @@ _vp, _i64, _int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 SYMBOLS = {
     "mirx_last_error": (ctypes.c_char_p, []),
     "mirx_version": (_int, []),
+    "mirx_set_tuning": (_int, [_int, _i64]),
     "mirx_index_create": (_int, [_int, _int, _int, ctypes.POINTER(_vp)]),
     "mirx_index_destroy": (None, [_vp]),
     "mirx_index_add": (_int, [_vp, _vp, _i64, _vp]),
@@ -109,7 +112,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 303          # include/mirx.h MIRX_VERSION this binding was written against
+ABI_VERSION = 304          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():

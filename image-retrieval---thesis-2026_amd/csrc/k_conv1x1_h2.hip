@@ -19,6 +19,8 @@
 // Contract otherwise as mirx_conv1x1_bn_relu_split3: y = act_out(W * act_in(x) + bias), NCHW, tile 128 output
 // channels x 128 (small launches) or 2 x 128 pixels, 16-channel stages, double-buffered LDS (32 / 48 KiB), weights by LDS
 // DMA, activations register-prefetched.  w2 = [cout / 128][cin / 16][2 terms][128 out][16 in] fp16.
+#include <atomic>
+
 #include "mirx_kernels.h"
 
 namespace mirx {
@@ -53,9 +55,6 @@ constexpr int PLANE_A = CM * KC * 2;   // bytes of one term of the weight stage 
 constexpr int PLANE_B = CP * KC * 2;
 #ifndef MIRX_C1H2_MIN_WG
 #define MIRX_C1H2_MIN_WG 256        // two-tile workgroups only when the launch has at least this many of them (one per CU; 512: -0.3 %)
-#endif
-#ifndef MIRX_C1H2_HALVES
-#define MIRX_C1H2_HALVES 1          // 2: the eight-wave arm (k_conv1x1_h2's HV) on y-terms launches of at least one such workgroup per CU
 #endif
 #ifndef MIRX_C1H2_NPT
 #define MIRX_C1H2_NPT 2             // pixel tiles per workgroup on large launches (1: the A/B arm)
@@ -94,12 +93,11 @@ __device__ __forceinline__ void pair_exchange(const u32x4 &p, const u32x4 &q, u3
     b = u32x4{b0, b1, b2, b3};
 }
 
-// HV = 2 (the A/B arm -DMIRX_C1H2_HALVES=2, y-terms layers with two pixel tiles only): ONE workgroup of eight waves takes the
-// pixels of two of the workgroups above -- waves 0-3 one half, waves 4-7 the other, each exactly as before -- against one
-// staged copy of the weights: half the L2 -> LDS weight stream per pixel (the stream costs 11 % of the forward),
-// for one barrier shared by eight waves instead of two independent workgroups per CU.
-template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED, int HV = 1>
-__global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
+// (An eight-wave arm -- ONE workgroup per CU, waves 0-3 and 4-7 each on two pixel tiles against one staged copy of the weights,
+// half the L2 -> LDS weight stream per pixel -- was built in round 3, parity-green and SLOWER (89.8 / 90.1 vs 88.5 / 88.5 ms
+// per forward): eight waves meeting at one barrier lose more than the shared operand saves.  Removed in round 4)
+template <bool PROLOGUE, bool RELU_OUT, bool YTERMS, int NPT, bool TABLED>
+__global__ __launch_bounds__(256, NPT == 2 ? 2 : 3) void k_conv1x1_h2(const float *__restrict__ x, int64_t xbs, int cin,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift,
                                                        const uint16_t *__restrict__ w2,
@@ -111,21 +109,17 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
                                                        float *__restrict__ y_inv_out, int64_t xps, int64_t yps) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     constexpr int KIMG = 8;                        // images a workgroup's pixels may span with a table row each (else: multiply)
-    __shared__ float sBias[CM], sOscH[HV][KIMG][CM];
+    __shared__ float sBias[CM], sOsc[KIMG][CM];
     // YTERMS with a table: the image's output scale 2^t is folded into BOTH constants of the epilogue's multiply-add (a power of
     // two: fma(a, s 2^t, b 2^t) = 2^t fma(a, s, b) exactly), which takes one multiply per value out of the epilogue
     constexpr bool YFOLD = YTERMS && TABLED;
-    __shared__ float sBiasYH[HV][YFOLD ? KIMG : 1][CM];
-    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int half_wg = HV == 2 ? wave_all >> 2 : 0, wave = wave_all & 3;       // which half of the workgroup, wave inside it
-    const int tid = threadIdx.x & 255;                                         // thread inside its half
-    float (*sOsc)[CM] = sOscH[half_wg];
-    float (*sBiasY)[CM] = sBiasYH[half_wg];
+    __shared__ float sBiasY[YFOLD ? KIMG : 1][CM];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t total = n * (int64_t)hw;
-    constexpr int STAGE_N = 2 * PLANE_A + HV * NPT * 2 * PLANE_B;  // bytes of one LDS stage
-    const int hb = half_wg * (NPT * 2 * PLANE_B);                   // this half's activation planes inside a stage
-    const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT * HV) + half_wg * (CP * NPT);
+    constexpr int STAGE_N = 2 * PLANE_A + NPT * 2 * PLANE_B;       // bytes of one LDS stage
+    const int64_t p0 = (int64_t)blockIdx.x * (CP * NPT);
     const int co0 = blockIdx.y * CM;
     const int nk = cin / KC;
 
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
 #else
     const int b_row = YTERMS ? ((b_px & ~31) | ((b_px & 15) << 1) | ((b_px >> 4) & 1)) : b_px;
 #endif
-    const int b_lds = 2 * PLANE_A + hb + b_row * 32 + ((b_kg ^ ((b_row >> 3) & 1)) << 4);   // + tile * 2 PLANE_B + term * PLANE_B
+    const int b_lds = 2 * PLANE_A + b_row * 32 + ((b_kg ^ ((b_row >> 3) & 1)) << 4);   // + tile * 2 PLANE_B + term * PLANE_B
     const int ep_px = YTERMS ? 16 * (lane & 1) + ((lane & 31) >> 1) : (lane & 31);     // this lane's pixel within its 32-block
     // A: the 8 KiB weight stage goes global -> LDS by DMA (buffer_load ... lds: lane l of a wave writes 16 B at
     // piece base + 16 l), two 1-KiB pieces per wave.  Piece p, lane l is LDS (term p / 4, row 32 (p & 3) +
@@ -172,8 +166,7 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
         (void *)(w2 + ((int64_t)blockIdx.y * nk) * (2 * CM * KC)), 0, nk * (2 * CM * KC * 2), 0x00020000);
     const int w_voff = (lane >> 1) * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) << 4);
     [[maybe_unused]] auto dma_w1 = [&](int kt, int buf, int i) {
-        if (HV == 2 && i) return;                                  // eight waves: one piece each
-        const int piece = HV == 2 ? wave_all : wave + 4 * i;
+        const int piece = wave + 4 * i;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_PTR(sm + buf * STAGE_N + piece * 1024), 16, w_voff,
                                                  kt * (2 * CM * KC * 2) + piece * 1024, 0, 0);
     };
@@ -197,11 +190,8 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
         for (int u = 0; u < NPT; ++u)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#ifdef MIRX_C1H2_SC1_LOADS              // the A/B arm: agent-scope loads (sc1) pass the vector L1 by, which then holds only the weight pieces: 90.2 / 90.3 vs 89.2 / 89.6 ms, slower
-                r[u][j] = __hip_atomic_load(xsrc[u] + ((int64_t)kt * KC + j) * in_hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
+                // (agent-scope `sc1` loads, which pass the vector L1 by so that it holds only weight pieces, measured slower: DESIGN 12)
                 r[u][j] = xsrc[u][((int64_t)kt * KC + j) * in_hw];
-#endif
             }
         if (PROLOGUE) {
 #pragma unroll
@@ -264,10 +254,10 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
         const int ra_ = wm * 64 + t * 32 + (lane & 31);
         fa[t] = ra_ * 32 + ((kg ^ ((ra_ >> 3) & 1)) << 4);
         const int rb_ = wn * 64 + t * 32 + (lane & 31);
-        fb[t] = 2 * PLANE_A + hb + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
+        fb[t] = 2 * PLANE_A + rb_ * 32 + ((kg ^ ((rb_ >> 3) & 1)) << 4);
     }
 
-    const unsigned img_first = (unsigned)(p0 < total ? p0 : total - 1) / (unsigned)hw;   // (HV = 2: the last workgroup's second half may hold no pixel)
+    const unsigned img_first = (unsigned)(p0 < total ? p0 : total - 1) / (unsigned)hw;
     const unsigned p_last = (unsigned)(p0 + CP * NPT - 1 < total ? p0 + CP * NPT - 1 : total - 1);
     constexpr bool tabled = TABLED;
 
@@ -289,30 +279,18 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
         // loads to registers must not be assumed to retire in one common order.  The loads of stage kt + 1 therefore
         // complete here too; they were issued a whole stage earlier (two register sets), which is what matters.
         C1_STAMP(st_store)
-#ifdef MIRX_C1H2_COUNTED
-        // experiment (round 3): wait only for the two DMA pieces -- the OLDEST operations in flight -- and leave the 8 NPT
-        // activation loads issued behind them in flight across the barrier.  tools/dma_order_probe.hip (5e8 words per variant,
-        // cold and hot DMA sources, loads behind them missing to HBM) finds a counted wait SAFE when program order is fenced
-        // (the sched_barrier between dma_w and load below): round 2's state-dependent errors were most likely loads hoisted
-        // above the DMA pieces.  State probe and the whole model suite are clean with it.  Measured: -2.7 % on the layers back to
-        // back, 45.2-45.4 k img/s either way on the whole forward -- not adopted, the drain is not what holds the layer.
-        if (NPT == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        C1_STAMP(st_wait)
-        __builtin_amdgcn_s_barrier();
-#else
+        // (A counted wait that keeps the activation loads in flight across the barrier -- safe once a sched_barrier fences the
+        // DMA pieces ahead of the loads, tools/dma_order_probe.hip -- bought 2.7 % on the layers back to back and nothing on
+        // the forward: DESIGN 12; the arm was removed in round 4.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C1_STAMP(st_wait)
         __syncthreads();
-#endif
         C1_STAMP(st_bar)
-#ifndef MIRX_C1H2_DMA_SPREAD
 #if defined(MIRX_C1H2_EXP_SKIP) && (MIRX_C1H2_EXP_SKIP & 1)          // diagnostic (wrong results): no weight DMA inside the K loop
         if (kt < 0)
 #endif
         dma_w(kt + 1 < nk ? kt + 1 : kt, cur ^ 1);         // branch-free tails: re-load the last stage
         __builtin_amdgcn_sched_barrier(0);                 // (the DMA pieces stay older than the loads behind them)
-#endif
         load(kt + 2 < nk ? kt + 2 : nk - 1, rnext, scn, shn);
         __builtin_amdgcn_sched_barrier(0);
         C1_STAMP(st_issue)
@@ -340,15 +318,6 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
                 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi][0], b[ni][0], c, 0, 0, 0);
                 acc[mi][ni] = c;
             }
-#ifdef MIRX_C1H2_DMA_SPREAD
-            // the A/B arm: a wave's issue stalls on every `buffer_load ... lds` piece; behind a row of MFMAs already queued the
-            // stall costs the matrix pipe nothing (as in k_gemm16), right behind the barrier it delays the whole stage.
-            // Measured SLOWER: 91.1 / 91.3 vs 90.2 / 90.7 ms per forward of 4096 images (same box, alternating) -- the pieces
-            // then land later than the next stage's wait; the 11 % the weight stream costs is not its issue slot.
-            __builtin_amdgcn_sched_barrier(0);
-            dma_w1(kt + 1 < nk ? kt + 1 : kt, cur ^ 1, mi);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         C1_STAMP(st_mfma)
         store(cur ^ 1, rstore, scs, shs);                  // stage kt + 1 (loaded one stage ago)
@@ -358,7 +327,7 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
     load(nk > 1 ? 1 : 0, rb, scb, shb);
     if (tid < CM) {
         const float bias_v = bias ? bias[co0 + tid] : 0.f;
-        if (half_wg == 0) sBias[tid] = bias_v;
+        sBias[tid] = bias_v;
         const float osc = oscale[co0 + tid];
         sOsc[0][tid] = osc;
         if (tabled) {
@@ -499,13 +468,8 @@ __global__ __launch_bounds__(256 * HV, HV == 2 ? 1 : NPT == 2 ? 2 : 3) void k_co
                 pair_exchange(l0, l1, al, bl);
                 const int64_t gofs = (int64_t)(2 * g) * hw;                    // records from group 0 to group g
                 const int half = (lane & 1) * 8;
-                // (-DMIRX_C1H2_NT_STORES, non-temporal stores for these records that no workgroup reads back: 90.6-91.0 ms either
-                // way on one box -- kept as the A/B arm)
-#ifdef MIRX_C1H2_NT_STORES
-#define C1_ST(P, V) __builtin_nontemporal_store(V, reinterpret_cast<u32x4 *>(P))
-#else
+                // (non-temporal stores for these records, which no workgroup reads back, measured equal: DESIGN 12)
 #define C1_ST(P, V) *reinterpret_cast<u32x4 *>(P) = V
-#endif
                 if (qa != 0xffffffffu) {
                     uint16_t *dst = yt + ((int64_t)qa + gofs) * 16 + half;
                     C1_ST(dst, ah);
@@ -555,6 +519,12 @@ extern "C" int mirx_debug_c1_stamps(unsigned long long *out) {
 }
 #endif
 
+// launches of fewer than this many 128 x 128 workgroups take the one-wave-per-tile kernel (mirx_set_tuning
+// MIRX_TUNE_CONV1X1_SMALL_MAX_WG; 0 switches the small kernel off -- the two kernels agree bit for bit, so this is speed only)
+static std::atomic<int> g_small_max_wg{128};
+void set_conv1x1_small_max_wg(int v) { g_small_max_wg.store(v < 0 ? 0 : v); }
+static int conv1x1_small_max_wg() { return g_small_max_wg.load(std::memory_order_relaxed); }
+
 hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
                              const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
                              int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
@@ -571,10 +541,14 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     const int64_t px = n * (int64_t)hw;
     if (px >= ((int64_t)1 << 31) - 2 * CP) return hipErrorInvalidValue;      // the kernel indexes pixels with 32 bits
     if (yterms && px >= ((int64_t)1 << 27)) return hipErrorInvalidValue;     // ... and the 32-byte records of y (16 per pixel) too
+    // small launches (the reference's own batch sizes): one wave per 32 x 32 tile, no LDS (k_conv1x1_h2s.hip) -- when this
+    // kernel's 128 x 128 tiles would leave most CUs without a workgroup
+    if (px * (cout / CM) < (int64_t)CP * conv1x1_small_max_wg())
+        return launch_conv1x1_h2_small(x, xbs, cin, scale, shift, w2, oscale, bias, n, hw, cout, relu_out, y, ybs, in_amax,
+                                       in_ks, in_kb, out_amax, y_ks, y_kb, y_inv_out, xps, yps, st);
     const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
-    const int hv = (MIRX_C1H2_HALVES == 2 && yterms && npt == 2 && px >= (int64_t)4 * CP * 256) ? 2 : 1;
-    const dim3 grid((unsigned)((px + CP * npt * hv - 1) / (CP * npt * hv)), (unsigned)(cout / CM));
-    const size_t lds = 2 * (size_t)(2 * PLANE_A + hv * npt * 2 * PLANE_B);
+    const dim3 grid((unsigned)((px + CP * npt - 1) / (CP * npt)), (unsigned)(cout / CM));
+    const size_t lds = 2 * (size_t)(2 * PLANE_A + npt * 2 * PLANE_B);
     unsigned *oa = reinterpret_cast<unsigned *>(out_amax);
     // the oscale table has 8 rows: a workgroup's CP * npt pixels span at most (CP * npt - 1) / hw + 2 images
     const bool tabled = (CP * npt - 1) / hw + 2 <= 8;
@@ -582,28 +556,23 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     {                                                                                                      \
         if (tabled) MIRX_H2KT(P, R, T, N, true) else MIRX_H2KT(P, R, T, N, false)                          \
     }
-#define MIRX_H2KT(P, R, T, N, TB) MIRX_H2KH(P, R, T, N, TB, 1)
-#define MIRX_H2KH(P, R, T, N, TB, H)                                                                       \
+#define MIRX_H2KT(P, R, T, N, TB)                                                                          \
     {                                                                                                      \
         static bool attr_set = false;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
         if (!attr_set) {                                                                                   \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB, H>), \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + H * N * 2 * PLANE_B)); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + N * 2 * PLANE_B)); \
             if (e != hipSuccess) return e;                                                                 \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB, H>), grid, dim3(256 * H), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
+        hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
                            n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, xps, yps); \
     }
 #define MIRX_H2C(P, R, T)                                                                                  \
     {                                                                                                      \
         if (npt == 2) MIRX_H2K(P, R, T, 2) else MIRX_H2K(P, R, T, 1)                                        \
     }
-    if (yterms && hv == 2) {
-#if MIRX_C1H2_HALVES == 2
-        if (tabled) MIRX_H2KH(true, true, true, 2, true, 2) else MIRX_H2KH(true, true, true, 2, false, 2)
-#endif
-    } else if (yterms) {
+    if (yterms) {
         MIRX_H2C(true, true, true)
     } else if (scale) {
         if (relu_out) MIRX_H2C(true, true, false) else MIRX_H2C(true, false, false)
@@ -612,7 +581,6 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     }
 #undef MIRX_H2K
 #undef MIRX_H2KT
-#undef MIRX_H2KH
 #undef MIRX_H2C
     return hipGetLastError();
 }

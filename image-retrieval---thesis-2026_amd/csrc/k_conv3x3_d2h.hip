@@ -277,6 +277,12 @@ hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const floa
     if (n > 65535 || !in_inv || !oscale) return hipErrorInvalidValue;
     if (!out_ps) out_ps = (int64_t)side * side;
     if (out_ps < (int64_t)side * side) return hipErrorInvalidValue;
+    // small launches (the reference's own batch sizes): one wave per block of 32 output pixels, no LDS (k_conv3x3_d2s.hip)
+    {
+        const int64_t wgs = side == 56 ? 14 * n : side == 28 ? 4 * n : side == 14 ? n : (n + 3) / 4;
+        if (wgs < conv3x3_small_max_wg())
+            return launch_conv3x3_d2s(yt, w2, oscale, n, side, out, out_bs, in_inv, out_range, out_ps, st);
+    }
 #ifndef MIRX_D2P_WAVES
 #define MIRX_D2P_WAVES 4          // 8: one 8-wave workgroup per CU on twice the pixels (the A/B arm, measured slower)
 #endif

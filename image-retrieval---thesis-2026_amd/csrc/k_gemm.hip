@@ -398,6 +398,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm(GemmArgs A) {
 // ================================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+struct RingEntry {     // a lane's pair of accumulator tiles that holds a passing score, parked in LDS by k_gemm16's K loop
+    f32x4 a0, a1;      // tiles (mi, n0) and (mi, n0 + 1): rows 16 mi + 4 (lane >> 4) + r, queries 16 n + (lane & 15)
+    unsigned tag;      // lane | mi << 6 | (n0 >> 1) << 9 | gallery tile << 10
+    unsigned pad[3];   // 48 bytes: the two tiles go out as one ds_write_b128 each
+};
+constexpr int RING_SLOTS = 64;       // per wave: 3 KiB, 24 KiB per workgroup (LDS: 131 + 3 + 24 = 158 of 160 KiB)
+constexpr int SPILL_SLOTS = 2048;    // per wave, global (96 KiB): what the ring overflowed into, kept until the workgroup's end
+constexpr int SPILL_PER_TILE = 1024; // the most one gallery tile can park: every (lane, tile pair) of the wave
+
 __device__ inline float vmax3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -471,7 +480,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 
     // thresholds of this workgroup's 256 queries: LDS, read back per gallery tile by the epilogue
     float *ltau = reinterpret_cast<float *>(lcnt + BN * WARPS_M);
+    // this wave's candidate ring (filter mode): passing scores are parked here by the K loop and handed to the global
+    // candidate regions in bulk -- the K loop then holds no global store (whose completion its per-K-tile vmcnt(0) would
+    // wait for) and no LDS atomic with a result to wait for
+    RingEntry *ring = reinterpret_cast<RingEntry *>(ltau + BN) + wave * RING_SLOTS;
+    int rcnt = 0, scnt = 0;                        // entries in the ring / in this wave's global spill area (wave-uniform: SGPRs)
+#ifdef MIRX_EXP_NOEPI      // diagnostic (results wrong): no score passes, the candidate path never runs
+    if (MODE == 0 && threadIdx.x < BN) ltau[threadIdx.x] = INFINITY;
+#else
     if (MODE == 0 && threadIdx.x < BN) ltau[threadIdx.x] = A.tau[q_row0 + threadIdx.x];
+#endif
 
     f32x4 acc[M_REP][N_REP];
 
@@ -486,60 +504,86 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     constexpr bool FUSE = MODE == 0 && !L2;
 #endif
 
-    // Candidate path of one PAIR of accumulator tiles (row tile mi, query tiles n0 and n0 + 1): about two of a wave's
-    // 2 048 scores pass per gallery tile, so this is cold code -- kept small (ONE copy of the push per call site: a
-    // wave-uniform loop takes every lane's passing values one at a time) because it is inlined at 16 + 16 places.
-    // No global atomics: the region (query, this workgroup's phase, this wave row) belongs to this wave alone and
-    // its fill count lives in LDS; the four lanes that share a query (lane & 15) claim slots with one LDS atomic each
-    // (a plain load / store of the shared counter would be a data race across lanes).  Rows beyond the region's
-    // slots go to the query's overflow list.  Everything is re-derived from an opaque copy of the lane id so that
-    // none of it (64-bit columns, pointers) is hoisted into the K loop's live registers -- the loop has none to spare.
-    auto emit_pair = [&](int64_t gt_, int mi, int n0, const f32x4 a0, const f32x4 a1, float t0, float t1) {
-        int el = lane;
-        asm volatile("" : "+v"(el));
-        const int quad = el >> 4, col = el & 15;
-        unsigned pm = 0;
+    // One parked entry -> the global candidate regions: its eight values against the two thresholds (the K loop only knows
+    // that at least one passes).  No global atomics: the region (query, this workgroup's phase, this wave row) belongs to
+    // this wave alone and its fill count lives in LDS; lanes that hold values of the same query claim slots with one LDS
+    // atomic each (a plain load / store of the shared counter would be a data race across lanes).  Rows beyond the region's
+    // slots go to the query's overflow list.
+    auto push_entry = [&](const f32x4 e0, const f32x4 e1, unsigned tag) __attribute__((always_inline)) {
+        const int el = tag & 63, mi = (tag >> 6) & 7, n0 = ((tag >> 9) & 1) * 2;
+        const int64_t row0 = (int64_t)(tag >> 10) * BM + wm * WM_ROWS + mi * 16 + 4 * (el >> 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pm |= (a0[r] > t0 ? 1u : 0u) << r;
-            pm |= (a1[r] > t1 ? 1u : 0u) << (4 + r);
-        }
-        const int64_t row0 = gt_ * BM + wm * WM_ROWS + mi * 16 + 4 * quad;
-        while (__any(pm != 0)) {
-            if (pm != 0) {
-                const int j = __builtin_ctz(pm);
-                pm &= pm - 1;
-                float v = a0[0];
-                v = j == 1 ? a0[1] : v;
-                v = j == 2 ? a0[2] : v;
-                v = j == 3 ? a0[3] : v;
-                v = j == 4 ? a1[0] : v;
-                v = j == 5 ? a1[1] : v;
-                v = j == 6 ? a1[2] : v;
-                v = j == 7 ? a1[3] : v;
-                const int64_t grow = (row0 + (j & 3)) * A.row_stride;
-                if (grow < A.n_rows) {                 // rows beyond the gallery exist in its last (partial) tile
-                    const int qi = wn * 64 + (n0 + (j >> 2)) * 16 + col;
-                    const int64_t qc = q_row0 + qi;
-                    const int c = atomicAdd(&lcnt[qi * WARPS_M + wm], 1);
-                    Cand cd;
-                    cd.s = v;
-                    cd.row = (int32_t)grow;
-                    if (c < A.slots) {
-                        A.cand[(qc * A.regions + (ph * WARPS_M + wm)) * A.slots + c] = cd;
-                    } else {
-                        const int p = atomicAdd(&A.ovf_cnt[qc], 1);
-                        if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
-                    }
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? e0[j & 3] : e1[j & 3];
+            const int qi = wn * 64 + (n0 + (j >> 2)) * 16 + (el & 15);
+            const int64_t grow = (row0 + (j & 3)) * A.row_stride;
+            // (rows beyond the gallery exist in its last, partial tile)
+            if (v > ltau[qi] && grow < A.n_rows) {
+                const int64_t qc = q_row0 + qi;
+                const int c = atomicAdd(&lcnt[qi * WARPS_M + wm], 1);
+                Cand cd;
+                cd.s = v;
+                cd.row = (int32_t)grow;
+                if (c < A.slots) {
+                    A.cand[(qc * A.regions + (ph * WARPS_M + wm)) * A.slots + c] = cd;
+                } else {
+                    const int p = atomicAdd(&A.ovf_cnt[qc], 1);
+                    if (p < CAND_OVF) A.ovf[qc * CAND_OVF + p] = cd;
                 }
             }
         }
+    };
+    // Everything parked so far goes out: at the END of the workgroup's life (about 500 entries per wave on the bench
+    // workload: the K loop itself only parks), or between two gallery tiles should the spill area be more than half full.
+    // The spill area is this wave's own and was written by this wave: its stores are complete after vmcnt(0), and it is
+    // read past the vector L1.
+    RingEntry *gspill = reinterpret_cast<RingEntry *>(A.spill) + ((int64_t)blockIdx.x * 8 + wave) * SPILL_SLOTS;
+    auto drain = [&]() __attribute__((always_inline)) {
+        if (__builtin_expect(scnt != 0, 0)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = lane; i < scnt; i += 64) {
+                const unsigned *src = reinterpret_cast<const unsigned *>(gspill + i);
+                unsigned w[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f32x4 e0, e1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e0[k] = __uint_as_float(w[k]);
+                    e1[k] = __uint_as_float(w[4 + k]);
+                }
+                push_entry(e0, e1, w[8]);
+            }
+            scnt = 0;
+        }
+        if (lane < rcnt) push_entry(ring[lane].a0, ring[lane].a1, ring[lane].tag);
+        rcnt = 0;
+    };
+
+    // Candidate path of one PAIR of accumulator tiles (row tile mi, query tiles n0 and n0 + 1) in which `hit` lanes hold a
+    // passing score: about two of a wave's 2 048 scores pass per gallery tile, but the slowest of the eight waves sets the
+    // pace of a K-tile, so this is kept to a dozen instructions: the hit lanes park both tiles and a tag in the wave's ring
+    // (ballot-ranked slots, two ds_write_b128 + one ds_write_b32); everything else happens in ring_flush().
+    auto emit_pair = [&](int64_t gt_, int mi, int n0, const f32x4 a0, const f32x4 a1, bool hit, unsigned long long bm) __attribute__((always_inline)) {
+        const int nh = __builtin_popcountll(bm);
+        if (__builtin_expect(rcnt + nh > RING_SLOTS, 0)) {     // wave-uniform, rare: the ring moves to the wave's spill area
+            if (lane < rcnt) gspill[scnt + lane] = ring[lane];
+            scnt += rcnt;
+            rcnt = 0;
+        }
+        if (hit) {
+            RingEntry *e = ring + rcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0));
+            e->a0 = a0;
+            e->a1 = a1;
+            e->tag = (unsigned)lane | (unsigned)mi << 6 | (unsigned)(n0 >> 1) << 9 | (unsigned)gt_ << 10;
+        }
+        rcnt = __builtin_amdgcn_readfirstlane(rcnt + nh);
     };
     // largest of an accumulator tile's four values in two instructions (fmaxf() would first canonicalise each
     // operand with a v_max_f32 x, x: four more instructions per tile in the fused check's issue budget)
 #define MIRX_TILEMAX(T) vmax2(vmax3((T)[0], (T)[1], (T)[2]), (T)[3])
 
-    auto epilogue = [&](int64_t gt_) {
+    auto epilogue = [&](int64_t gt_) __attribute__((always_inline)) {
         int el = lane;
         asm volatile("" : "+v"(el));
         const int quad = el >> 4, col = el & 15;
@@ -588,9 +632,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                 }
                 if (__builtin_expect(__any((mx0 > tau[n0]) | (mx1 > tau[n0 + 1])), 0)) {
 #pragma unroll
-                    for (int mi = 0; mi < M_REP; ++mi)
-                        if (__any((mr0[mi] > tau[n0]) | (mr1[mi] > tau[n0 + 1])))
-                            emit_pair(gt_, mi, n0, acc[mi][n0], acc[mi][n0 + 1], tau[n0], tau[n0 + 1]);
+                    for (int mi = 0; mi < M_REP; ++mi) {
+                        const bool hit = (mr0[mi] > tau[n0]) | (mr1[mi] > tau[n0 + 1]);
+                        const unsigned long long bm = __ballot(hit);
+                        if (bm) emit_pair(gt_, mi, n0, acc[mi][n0], acc[mi][n0 + 1], hit, bm);
+                    }
                 }
             }
         }
@@ -605,8 +651,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 
     static_assert(A_TILE_BYTES == 32768 && BN * ROW_BYTES == 32768, "buffer toggle assumes 32 KiB tiles");
     // OTHER = 0: the current buffer, 1: the other one
+#ifdef MIRX_EXP_NOLDS      // diagnostic (results wrong): fragments are never refreshed
+#define MIRX_LDA(S, OTHER, MI) fa[MI]
+#define MIRX_LDB(S, OTHER, NI) fb[NI]
+#else
 #define MIRX_LDA(S, OTHER, MI) (*reinterpret_cast<const bf16x8 *>(smem + (acur ^ ((OTHER) << 15) ^ ((S) << 6)) + (MI) * 16 * ROW_BYTES))
 #define MIRX_LDB(S, OTHER, NI) (*reinterpret_cast<const bf16x8 *>(smem + (bcur ^ ((OTHER) << 15) ^ ((S) << 6)) + (NI) * 16 * ROW_BYTES))
+#endif
     // Z = 1: the first slice of a gallery tile starts its 32 accumulator tiles from the constant 0 (no
     // 128 v_mov per tile)
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -617,8 +668,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     {                                                                                                            \
         const float m0_ = MIRX_TILEMAX(acc[MI][N0]);                                                             \
         const float m1_ = MIRX_TILEMAX(acc[MI][(N0) + 1]);                                                       \
-        if (__builtin_expect(__any((m0_ > ftau[N0]) | (m1_ > ftau[(N0) + 1])), 0))                               \
-            emit_pair(gt_prev, MI, N0, acc[MI][N0], acc[MI][(N0) + 1], ftau[N0], ftau[(N0) + 1]);                \
+        const bool hit_ = (m0_ > ftau[N0]) | (m1_ > ftau[(N0) + 1]);                                             \
+        const unsigned long long bm_ = __ballot(hit_);                                                           \
+        if (__builtin_expect(bm_ != 0, 0)) emit_pair(gt_prev, MI, N0, acc[MI][N0], acc[MI][(N0) + 1], hit_, bm_); \
     }
 #define MIRX_MFMA2Z(MI, N0, Z)                                                                         \
     if constexpr ((Z) && FUSE) MIRX_CHECK2(MI, N0)                                                     \
@@ -814,6 +866,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #ifdef MIRX_EXP_CYCLES
         const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (MODE == 0) {
+            // (never on the bench workload: a tile parks ~2 entries per wave; the area holds 2048)
+            if (__builtin_expect(scnt > SPILL_SLOTS - SPILL_PER_TILE, 0)) drain();
+        }
         if constexpr (FUSE) {
 #pragma unroll
             for (int ni = 0; ni < N_REP; ++ni) ftau[ni] = ltau[wn * 64 + ni * 16 + (lane & 15)];
@@ -849,6 +905,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
                (double)(__builtin_amdgcn_s_memtime() - life0) / cy_n);
 #endif
     if (MODE == 0) {
+        drain();
         __syncthreads();
         for (int i = threadIdx.x; i < BN * WARPS_M; i += 512) {
             const int c = lcnt[i];
@@ -896,7 +953,8 @@ template <int BN, int MODE>
 hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {
     GemmArgs a = a0;
     const size_t lds = 2 * (size_t)A_TILE_BYTES + 2 * (size_t)BN * ROW_BYTES +
-                       (MODE == 0 ? (size_t)BN * (8 / (BN / 64)) * sizeof(int) + (size_t)BN * sizeof(float) : 0);
+                       (MODE == 0 ? (size_t)BN * (8 / (BN / 64)) * sizeof(int) + (size_t)BN * sizeof(float) +
+                                        (BN == 256 ? (size_t)8 * RING_SLOTS * sizeof(RingEntry) : 0) : 0);
     const Plan plan = make_plan(a.n_rows, a.nq_pad, BN, device_cus() / 8 * 8);
     if (plan.ngt <= 0 || plan.nqt <= 0) return hipSuccess;
     a.nph = plan.nph;
@@ -904,6 +962,8 @@ hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {
         return hipErrorInvalidValue;
     // a tile's byte span must fit the 32-bit buffer offsets
     if ((int64_t)BM * a.row_stride * a.dimp * 2 > 0x7FFFFFFF) return hipErrorInvalidValue;
+    if (plan.ngt >= ((int64_t)1 << 22)) return hipErrorInvalidValue;      // k_gemm16's ring tags hold the gallery tile in 22 bits
+    if (MODE == 0 && BN == 256 && !a.spill) return hipErrorInvalidValue;
     hipError_t e;
     if constexpr (BN == 256) {
         if (use_mfma16()) {
@@ -947,6 +1007,8 @@ hipError_t launch_mode(const GemmArgs &a, int bn, hipStream_t st) {
 }
 
 }  // namespace
+
+size_t gemm_spill_bytes() { return (size_t)(device_cus() / 8 * 8) * 8 * SPILL_SLOTS * sizeof(RingEntry); }
 
 int gemm_query_tile(int64_t nq) { return nq <= 64 ? 64 : (nq <= 128 ? 128 : 256); }
 int gemm_groups_per_tile(int bn) { return 8 / (bn / 64); }

@@ -76,7 +76,7 @@ struct mirx_index {
     size_t ev_used = 0;
     // workspace
     DevBuf q32p, q16, qnorm, tau, cnt, cand, ovf_cnt, ovf, groupmax, fail_list, retry_list, tau2, q16r, taur,
-        scores, stage, rankwork;
+        scores, stage, rankwork, spill;
     int *fail_count = nullptr;            // device
     mirx_search_stats *stats_dev = nullptr;
     int *fail_count_host = nullptr;       // pinned
@@ -258,6 +258,7 @@ int batch_front(mirx_index *ix, const float *qb, int64_t nb, int k, const int64_
     MIRX_HIP(ix->cand.ensure((size_t)nb_pad * regions * slots * sizeof(Cand)));
     MIRX_HIP(ix->ovf_cnt.ensure((size_t)nb_pad * sizeof(int)));
     MIRX_HIP(ix->ovf.ensure((size_t)nb_pad * CAND_OVF * sizeof(Cand)));
+    MIRX_HIP(ix->spill.ensure(gemm_spill_bytes()));
     MIRX_HIP(ix->fail_list.ensure((size_t)nb_pad * sizeof(int32_t)));
     MIRX_HIP(ix->retry_list.ensure((size_t)nb_pad * sizeof(int32_t)));
     MIRX_HIP(ix->tau2.ensure((size_t)nb_pad * sizeof(float)));
@@ -274,6 +275,7 @@ int batch_front(mirx_index *ix, const float *qb, int64_t nb, int k, const int64_
     ga.cand = ix->cand.as<Cand>();
     ga.ovf_cnt = ix->ovf_cnt.as<int>();
     ga.ovf = ix->ovf.as<Cand>();
+    ga.spill = ix->spill.p;
     if (ix->force_tau_bits != 0x7fc00000u) {
         // test hook: one fixed threshold for every query
         std::vector<float> t((size_t)nb_pad, INFINITY);
@@ -479,6 +481,21 @@ extern "C" {
 const char *mirx_last_error(void) { return g_err.c_str(); }
 int mirx_version(void) { return MIRX_VERSION; }
 
+int mirx_set_tuning(int key, int64_t value) {
+    switch (key) {
+        case MIRX_TUNE_CONV1X1_SMALL_MAX_WG:
+            MIRX_CHECK(value >= 0 && value <= (1 << 20), "set_tuning: conv1x1 small-launch limit out of range");
+            set_conv1x1_small_max_wg((int)value);
+            return MIRX_OK;
+        case MIRX_TUNE_CONV3X3_SMALL_MAX_WG:
+            MIRX_CHECK(value >= 0 && value <= (1 << 20), "set_tuning: conv3x3 small-launch limit out of range");
+            set_conv3x3_small_max_wg((int)value);
+            return MIRX_OK;
+        default:
+            return fail(MIRX_EINVAL, "set_tuning: unknown key");
+    }
+}
+
 int mirx_index_create(int dim, int metric, int device, mirx_index **out) {
     MIRX_CHECK(out, "index_create: out is null");
     *out = nullptr;
@@ -524,7 +541,7 @@ void mirx_index_destroy(mirx_index *ix) {
     if (ix->pend_ev) (void)hipEventDestroy(ix->pend_ev);
     for (DevBuf *b : {&ix->q32p, &ix->q16, &ix->qnorm, &ix->tau, &ix->cnt, &ix->cand, &ix->ovf_cnt, &ix->ovf, &ix->groupmax,
                       &ix->fail_list, &ix->retry_list, &ix->tau2, &ix->q16r, &ix->taur, &ix->scores, &ix->stage,
-                      &ix->rankwork})
+                      &ix->rankwork, &ix->spill})
         b->release();
     delete ix;
 }

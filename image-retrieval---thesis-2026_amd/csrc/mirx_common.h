@@ -6,6 +6,21 @@
 
 #include "../../include/mirx.h"
 
+// ---- diagnostic builds ----------------------------------------------------------------------------------------------
+// A few kernels carry arms that give WRONG RESULTS on purpose (a phase skipped, raw bits stored instead of values, operands
+// never refreshed) or add cycle stamps / printf, to attribute a kernel's time.  The macros below select them, and they are
+// honoured only together with -DMIRX_DIAG: the shipped library never defines it (csrc/Makefile refuses a CXXFLAGS that
+// carries any -DMIRX_ switch; the diag-* targets build such objects into exp/ under other names).
+#if !defined(MIRX_DIAG) &&                                                                                             \
+    (defined(MIRX_EXP_NODMA) || defined(MIRX_EXP_NOBAR) || defined(MIRX_EXP_NOEPI) || defined(MIRX_EXP_NOLDS) ||         \
+     defined(MIRX_EXP_SLOTS) || defined(MIRX_EXP_SAMEA) || defined(MIRX_EXP_NOA) || defined(MIRX_EXP_NOB) ||             \
+     defined(MIRX_EXP_CYCLES) || defined(MIRX_C1H2_EXP_SKIP) || defined(MIRX_C1H2_EXP_SPLIT) ||                          \
+     defined(MIRX_C1H2_EXP_ONE_MFMA) || defined(MIRX_C1H2_STAMPS) || defined(MIRX_LT2_EXP) || defined(MIRX_LH2_EXP) ||   \
+     defined(MIRX_DF_EXP) || defined(MIRX_DF_STAMPS) || defined(MIRX_DW_STAMPS) || defined(MIRX_STEM_EXP) ||             \
+     defined(MIRX_W3_CYCLES))
+#error "a MIRX diagnostic switch without -DMIRX_DIAG: these arms give wrong results or alter timing and must never reach libmirx.so"
+#endif
+
 namespace mirx {
 
 // ---- error plumbing -------------------------------------------------------------------

@@ -90,6 +90,14 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
                              float *out_amax, float y_ks, float y_kb, float *y_inv_out, int64_t xps, int64_t yps,
                              hipStream_t st);
 
+void set_conv1x1_small_max_wg(int v);      // mirx_set_tuning(MIRX_TUNE_CONV1X1_SMALL_MAX_WG)
+// k_conv1x1_h2s.hip: the same contract for small launches (one wave per 32 x 32 tile, no LDS); bit-identical results
+hipError_t launch_conv1x1_h2_small(const float *x, int64_t xbs, int cin, const float *scale, const float *shift,
+                                   const uint16_t *w2, const float *oscale, const float *bias, int64_t n, int hw, int cout,
+                                   int relu_out, float *y, int64_t ybs, const float *in_amax, float in_ks, float in_kb,
+                                   float *out_amax, float y_ks, float y_kb, float *y_inv_out, int64_t xps, int64_t yps,
+                                   hipStream_t st);
+
 // ---- k_linear_h2.hip: the token-major Linear on two fp16 terms per operand (3 MFMAs per product) ----
 hipError_t launch_linear_h2(const float *x, int64_t m, int k, const uint16_t *w2, const float *bias, int n, int act,
                             const float *res, const float *gamma, float x_scale, float out_scale, float *y,
@@ -141,6 +149,12 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
                               int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
 
+// k_conv3x3_d2s.hip: the same contract for small launches (one wave per 32 output pixels, no LDS); bit-identical results
+hipError_t launch_conv3x3_d2s(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
+void set_conv3x3_small_max_wg(int v);      // mirx_set_tuning(MIRX_TUNE_CONV3X3_SMALL_MAX_WG)
+int conv3x3_small_max_wg();
+
 // ---- k_attention.hip --------------------------------------------------------------------
 hipError_t launch_attention(const float *qkv, int64_t batch, int n, int heads, int head_dim, float scale, float *out,
                             hipStream_t st);
@@ -188,6 +202,7 @@ struct GemmArgs {
     Cand *cand;            // [nq_pad, regions, slots]
     int *ovf_cnt;          // [nq_pad]           (zeroed per search)
     Cand *ovf;             // [nq_pad, CAND_OVF]
+    void *spill;           // gemm_spill_bytes(): per-wave overflow area of the 256-query kernel's candidate rings
     // group-max mode
     float *groupmax;       // [nq_pad, ngroups]
     int ngroups;
@@ -195,6 +210,7 @@ struct GemmArgs {
 int gemm_query_tile(int64_t nq);                 // query-tile width chosen for nq (64/128/256)
 // Producer regions per query and slots per region of the filter GEMM for this problem.
 void gemm_plan(int64_t n_rows, int64_t nq_pad, int bn, int *regions, int *slots);
+size_t gemm_spill_bytes();                       // workspace the filter GEMM needs behind GemmArgs::spill
 int gemm_groups_per_tile(int bn);                // group-max groups per 256-row gallery tile
 hipError_t launch_gemm_filter(const GemmArgs &a, int bn, hipStream_t st);
 hipError_t launch_gemm_groupmax(const GemmArgs &a, int bn, hipStream_t st);

@@ -29,6 +29,7 @@ unless a local state dict is given via ``weights=``.
 import ctypes
 import dataclasses
 import math
+import operator
 from collections import OrderedDict
 
 import torch
@@ -850,6 +851,9 @@ def _conv_patch_tokens(conv, x, ln2d=None, nchw_out=False):
     return _linear_s3(pl, rows)
 
 
+_TENSOR_VERSION = operator.attrgetter("_version")
+
+
 class DenseNet121(_Configurable, nn.Module):
     """Reference model.py:42-84, MI355X-native inference path."""
 
@@ -887,55 +891,79 @@ class DenseNet121(_Configurable, nn.Module):
 
     # -- MI355X inference path -------------------------------------------------------------------
     # The folded / pre-split weights are derived from the parameters and BatchNorm buffers; they are rebuilt whenever
-    # any of those changed: tensor versions are summed on every forward (in-place edits, load_state_dict through a
-    # parent module and copy_ all bump them), device moves and dtype casts arrive through _apply.
+    # any of those changed.  Routes that announce themselves drop the cache at once: load_state_dict (this module's own
+    # and, through the pre-hook, a parent's), _apply (device moves, dtype casts), train().  What remains -- an in-place
+    # edit of a parameter, a replaced tensor object -- is caught by ONE pass per forward over the watched tensors
+    # (versions and identities: ~0.1 ms for the 604 tensors; it was two passes of 0.22 ms, 18 % of a one-image forward).
+    def _watch_lists(self):
+        w = self.__dict__.get("_mirx_watch")
+        if w is None:
+            dicts, keys = [], []
+            for m in self.densenet121[0].modules():
+                for d in (m._parameters, m._buffers):
+                    for k in d:
+                        if d[k] is not None and k != "num_batches_tracked":       # not read by an eval-mode BatchNorm
+                            dicts.append(d)
+                            keys.append(k)
+            w = (dicts, keys, [d[k] for d, k in zip(dicts, keys)])
+            self.__dict__["_mirx_watch"] = w
+        return w
+
     def _weights_version(self):
         """(sum of tensor versions, sum of tensor identities) over every parameter and BatchNorm buffer of the feature
-        stack, read through the owning modules' dicts on every forward: in-place edits bump the first, a REPLACED tensor
-        object (load_state_dict(assign=True), `conv.weight = nn.Parameter(..)`) changes the second."""
-        watch = self.__dict__.get("_mirx_watch")
-        if watch is None:
-            watch = []
-            for m in self.densenet121[0].modules():
-                watch += [(m._parameters, k) for k in m._parameters] + [(m._buffers, k) for k in m._buffers]
-            self.__dict__["_mirx_watch"] = watch
-        ver = ident = 0
-        for d, k in watch:
-            t = d[k]
-            if t is not None:
-                ver += t._version
-                ident += id(t)
-        return ver, ident
+        stack: in-place edits bump the first, a REPLACED tensor object (`conv.weight = nn.Parameter(..)`) changes the second."""
+        dicts, keys, tens = self._watch_lists()
+        ident = sum(map(id, map(dict.__getitem__, dicts, keys)))
+        if ident != self.__dict__.get("_mirx_watch_ident"):
+            self.__dict__.pop("_mirx_watch", None)                 # a tensor object was replaced: take the new objects
+            dicts, keys, tens = self._watch_lists()
+            self.__dict__["_mirx_watch_ident"] = ident = sum(map(id, tens))
+        return sum(map(_TENSOR_VERSION, tens)), ident
 
     def _cache(self):
         ver = self._weights_version()
-        if self._infer_cache is None or self._infer_cache.get("_version") != ver:
-            self._prepare_inference()
-            if next(self.densenet121[0].parameters()).is_cuda:
-                self._prepare_h2(self._infer_cache)
-                # the folded / split weights are built by kernels on the CALLING stream; a first use from several streams
-                # at once (bench.py's embed streams) must not read them half-built: one device-wide wait per rebuild
-                torch.cuda.synchronize(next(self.densenet121[0].parameters()).device)
-            self._infer_cache["_version"] = ver
-        return self._infer_cache
+        cache = self._infer_cache
+        if cache is None or cache.get("_version") != ver:
+            cache = self._prepare_inference()
+            cache["_version"] = ver
+        if cache.get("_cuda"):
+            # the folded / split weights are built by kernels on the stream that was current at the time; a stream that
+            # has not seen them yet (bench.py's embed streams) waits for the newest build's event -- no device-wide sync
+            sid = torch.cuda.current_stream().stream_id
+            if sid not in cache["_seen"]:
+                torch.cuda.current_stream().wait_event(cache["_built"])
+                cache["_seen"].add(sid)
+        return cache
+
+    @staticmethod
+    def _mark_built(cache):
+        """Call after enqueueing work that fills `cache` on the current stream."""
+        if cache.get("_cuda"):
+            ev = torch.cuda.Event()
+            ev.record()
+            cache["_built"] = ev
+            cache["_seen"] = {torch.cuda.current_stream().stream_id}
+
+    def _drop_cache(self, *a, **k):
+        self._infer_cache = None
+        self.__dict__.pop("_mirx_watch", None)
 
     def train(self, mode=True):
-        self._infer_cache = None
+        self._drop_cache()
         return super().train(mode)
 
     def load_state_dict(self, *a, **k):
-        self._infer_cache = None
-        self.__dict__.pop("_mirx_watch", None)
+        self._drop_cache()
         return super().load_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._infer_cache = None
-        self.__dict__.pop("_mirx_watch", None)
+        self._drop_cache()
         return super()._apply(fn, *a, **k)
 
     def _prepare_inference(self):
         """Fold every eval-mode BatchNorm once: norm1/transition norm -> (scale, shift) for the
-        fused HIP passes; norm2 -> into conv1's weights and bias."""
+        fused HIP passes; norm2 -> into conv1's weights and bias.  The operands of the legacy (three-bf16-term /
+        Winograd) kernels are NOT built here: _ensure_legacy() does that when an input takes that path."""
         f = self.densenet121[0]
         cache = {}
         for name, m in f.named_children():
@@ -946,25 +974,41 @@ class DenseNet121(_Configurable, nn.Module):
                     sc2, sh2 = _bn_affine(layer.norm2)
                     w1 = (layer.conv1.weight.detach().float() * sc2.view(-1, 1, 1, 1)).contiguous()
                     w1t = w1.view(w1.shape[0], w1.shape[1]).t().contiguous()       # [cin, 128] for the HIP GEMM
-                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t,
-                                  (_winograd_weights(layer.conv2.weight), _winograd_weights_split3(layer.conv2.weight),
-                                   _conv3x3_weights_split3(layer.conv2.weight)),
-                                  _split3_weights(w1.view(w1.shape[0], w1.shape[1])))
+                    blk[lname] = (sc1, sh1, w1, sh2, torch.ones_like(sh2), w1t, None, None)
                 cache[name] = blk
             elif name.startswith("transition"):
                 wt = m.conv.weight.detach().float()
-                cache[name] = _bn_affine(m.norm) + (wt.view(wt.shape[0], wt.shape[1]).t().contiguous(),
-                                                    _split3_weights(wt.view(wt.shape[0], wt.shape[1])))
+                cache[name] = _bn_affine(m.norm) + (wt.view(wt.shape[0], wt.shape[1]).t().contiguous(), None)
         cache["norm0"] = _bn_affine(f.norm0)
         cache["norm5"] = _bn_affine(f.norm5)
+        cache["_cuda"] = f.conv0.weight.is_cuda
         self._infer_cache = cache
+        self._mark_built(cache)
         return cache
 
-    def _features_fused(self, x):
+    def _ensure_legacy(self, cache):
+        """Operands of the kernels that serve inputs other than 224 x 224 (three bf16 terms, Winograd): built on first use."""
+        if cache.get("_legacy"):
+            return
+        f = self.densenet121[0]
+        for name, m in f.named_children():
+            if name.startswith("denseblock"):
+                for lname, layer in m.items():
+                    e = cache[name][lname]
+                    w1 = e[2]
+                    cache[name][lname] = e[:6] + ((_winograd_weights(layer.conv2.weight), _winograd_weights_split3(layer.conv2.weight),
+                                                   _conv3x3_weights_split3(layer.conv2.weight)),
+                                                  _split3_weights(w1.view(w1.shape[0], w1.shape[1])))
+            elif name.startswith("transition"):
+                wt = m.conv.weight.detach().float()
+                cache[name] = cache[name][:3] + (_split3_weights(wt.view(wt.shape[0], wt.shape[1])),)
+        cache["_legacy"] = True
+        self._mark_built(cache)
+
+    def _features_fused(self, x, cache):
         """-> (feature map before norm5 [B,1024,h,w])"""
         f = self.densenet121[0]
         lib = _lib.load()
-        cache = self._cache()
         if x.dtype == torch.uint8:
             if self._h2_ok(x):
                 return self._features_h2(x.contiguous(), cache)          # normalised inside the stem kernel
@@ -973,6 +1017,7 @@ class DenseNet121(_Configurable, nn.Module):
         b, _, h, w = x.shape
         if self._h2_ok(x):
             return self._features_h2(x, cache)
+        self._ensure_legacy(cache)
         cfg = _cfg(self)
         if cfg.hip_stem and h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8:
             sc, sh = cache["norm0"]
@@ -980,6 +1025,7 @@ class DenseNet121(_Configurable, nn.Module):
             if cfg.stem_three_bf16 and b <= 65535:
                 if "conv0_w3" not in cache:
                     cache["conv0_w3"] = _stem_weights_split3(f.conv0.weight)
+                    self._mark_built(cache)
                 _lib.check(lib.mirx_stem_conv7_bn_relu_pool_split3(_ptr(x), _ptr(cache["conv0_w3"]), _ptr(sc), _ptr(sh),
                                                                    b, h, w, _ptr(y), _stream(x.device)), "mirx_stem_split3")
             else:
@@ -1036,6 +1082,7 @@ class DenseNet121(_Configurable, nn.Module):
                 h2[name] = {"sc": sc, "sh": sh, "w2": w2, "osc": osc, "ks": float(sc.abs().max()), "kb": float(sh.abs().max())}
         cache["conv0_w2"] = _stem_weights_split2h(f.conv0.weight)
         cache["h2"] = h2
+        self._mark_built(cache)
         return h2
 
     def _features_h2(self, x, cache):
@@ -1101,10 +1148,9 @@ class DenseNet121(_Configurable, nn.Module):
         self.__dict__["_mirx_last_ranges"] = ranges            # kept for diagnostics (tools/h2_state_probe.py)
         return buf
 
-    def _head_fused(self, fmap, normalize):
-        f = self.densenet121[0]
+    def _head_fused(self, fmap, normalize, cache=None):
         lib = _lib.load()
-        sc, sh = self._cache()["norm5"]
+        sc, sh = (cache or self._cache())["norm5"]
         fmap = fmap.contiguous()
         b, c, h, w = fmap.shape
         out = torch.empty((b, c), dtype=torch.float32, device=fmap.device)
@@ -1117,9 +1163,10 @@ class DenseNet121(_Configurable, nn.Module):
         fused = x.is_cuda and not self.training and not torch.is_grad_enabled()
         if fused:
             with torch.cuda.device(x.device):
-                fmap = self._features_fused(x)
+                cache = self._cache()                  # ONE validity check of the folded weights per forward
+                fmap = self._features_fused(x, cache)
                 plain_head = self.fc is None and self.classification_head is None
-                x = self._head_fused(fmap, normalize=plain_head)
+                x = self._head_fused(fmap, normalize=plain_head, cache=cache)
                 if plain_head:
                     return x                       # already unit-norm (model.py:83)
         else:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 303
+#define MIRX_VERSION 304
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -79,6 +79,20 @@ typedef struct mirx_search_stats {
 
 const char *mirx_last_error(void);
 int mirx_version(void);
+
+/*
+ * Process-wide kernel-selection knobs.  They choose between kernels that return the SAME bits, so they change speed only
+ * (the tests use them to run both kernels of a pair on one input).  No reference analogue: the reference leaves such
+ * choices to cuDNN / MIOpen heuristics behind model(x) (model.py:71-84).
+ *   MIRX_TUNE_CONV1X1_SMALL_MAX_WG  a 1x1 convolution of fewer than this many 128-channel x 128-pixel workgroups runs as
+ *                                   one wave per 32 x 32 tile (small batches: test.py:1513 B = 64, milvus_retrieval.py:53-66
+ *                                   B = 1); 0 = never.  Default 128.
+ *   MIRX_TUNE_CONV3X3_SMALL_MAX_WG  the same for the dense layer's 3x3 convolution: fewer strip workgroups than this ->
+ *                                   one wave per 32 output pixels; 0 = never.  Default 96.
+ */
+#define MIRX_TUNE_CONV1X1_SMALL_MAX_WG 1
+#define MIRX_TUNE_CONV3X3_SMALL_MAX_WG 2
+int mirx_set_tuning(int key, int64_t value);
 
 /*
  * Index lifetime.  Replaces: Collection(name, schema) + create_index + load

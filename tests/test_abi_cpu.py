@@ -20,7 +20,7 @@ def test_header_symbols_all_bound_and_exported():
     assert len(names) >= 15
     assert sorted(L.SYMBOLS) == names, "ctypes table and include/mirx.h disagree"
     lib = L.load()                      # raises if any symbol is missing from the .so
-    assert lib.mirx_version() == L.ABI_VERSION == 303
+    assert lib.mirx_version() == L.ABI_VERSION == 304
     for n in names:
         assert hasattr(lib, n)
 
@@ -82,3 +82,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/_build" not in src and "liboracle" not in src, f
+
+
+def test_diagnostic_switches_cannot_reach_the_shipped_library():
+    """kernels carry "results wrong, timing only" arms behind MIRX_* macros.  The shipped Makefile target refuses
+    a CXXFLAGS with any -DMIRX_ switch, and the sources refuse such a macro without -DMIRX_DIAG (which only the diag-*
+    targets pass, building into exp/ under other names)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "image-retrieval---thesis-2026_amd", "csrc")
+    r = subprocess.run(["make", "-n", "-C", csrc, "CXXFLAGS=-O3 -DMIRX_EXP_NOEPI"], capture_output=True, text=True)
+    assert r.returncode != 0 and "carries a -DMIRX_ switch" in r.stderr
+    hipcc = "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        base = [hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-E", "-o", os.devnull]
+        bad = subprocess.run(base + ["-DMIRX_C1H2_EXP_SKIP=2", os.path.join(csrc, "k_conv1x1_h2.hip")], capture_output=True, text=True)
+        assert bad.returncode != 0 and "without -DMIRX_DIAG" in bad.stderr
+        ok = subprocess.run(base + ["-DMIRX_DIAG", "-DMIRX_C1H2_EXP_SKIP=2", os.path.join(csrc, "k_conv1x1_h2.hip")], capture_output=True, text=True)
+        assert ok.returncode == 0, ok.stderr[-500:]

@@ -22,6 +22,19 @@ def test_plain_command_starts_its_own_ranks_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] == 3.0        # both ranks took part in the all-reduce
+    # the line proves by itself which backend carried the collectives and who the ranks were
+    assert d["collective_backend"] == "gloo" and d["rehearsal"] is False
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and [r["local_rank"] for r in d["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in d["ranks"]}) == 2
+
+
+def test_rehearsal_switch_is_refused_where_more_than_one_gpu_is_visible():
+    r = _run({"MIRX_BENCH_REHEARSE": "1", "MIRX_BENCH_SELFTEST_VISIBLE_GPUS": "8"})
+    assert r.returncode == 4 and "MIRX_BENCH_REHEARSE" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    # on a one-GPU box the rehearsal stays available (the builder's only way to run two ranks)
+    r = _run({"MIRX_BENCH_REHEARSE": "1", "MIRX_BENCH_SELFTEST_VISIBLE_GPUS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_a_failing_rank_makes_the_plain_command_fail():

@@ -307,11 +307,25 @@ def test_split3_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu):
     assert bool((ybuf[:, cout:] == -5.0).all())
 
 
+@pytest.fixture(params=["tiled", "small"])
+def conv1x1_kernel(request):
+    """Both kernels behind mirx_conv1x1_bn_relu_split2h[_terms]: k_conv1x1_h2 (128 x 128 tiles through LDS) and k_conv1x1_h2s
+    (one wave per 32 x 32 tile, the small-launch kernel) -- selected by launch size in production, forced here."""
+    from mirx import _lib
+    lib = _lib.load()
+    for key in (_lib.TUNE_CONV1X1_SMALL_MAX_WG, _lib.TUNE_CONV3X3_SMALL_MAX_WG):       # the 3x3 conv has the same pair of kernels
+        _lib.check(lib.mirx_set_tuning(key, 0 if request.param == "tiled" else 1 << 20), "set_tuning")
+    yield request.param
+    _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV1X1_SMALL_MAX_WG, 128), "set_tuning")
+    _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, 96), "set_tuning")
+
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,hw,n,prologue,relu,mag", [(256, 128, 196, 3, True, True, 1.0), (512, 128, 49, 5, True, True, 40.0),
                                                              (1024, 512, 49, 2, False, False, 1e-3), (64, 128, 3136, 1, True, True, 300.0),
                                                              (992, 128, 37, 3, True, True, 1.0)])
-def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
+def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag, conv1x1_kernel):
     """mirx_conv1x1_bn_relu_split2h (two fp16 terms per operand, three MFMAs per product; the range of every image read from
     the input's range row) against a float64 restatement: fp32-grade (3e-6 relative to the largest output) at any input
     magnitude, every image's output range published exactly, bytes beyond the channel prefix untouched; a non-finite range
@@ -365,8 +379,114 @@ def test_split2h_conv1x1_matches_float64(cin, cout, hw, n, prologue, relu, mag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,hw,n,terms", [(64, 128, 3136, 1, True), (256, 128, 784, 3, True), (512, 128, 196, 5, True),
+                                                 (1008, 128, 196, 1, True), (992, 128, 49, 7, True), (512, 128, 49, 1, True),
+                                                 (256, 128, 784, 2, False), (512, 256, 196, 3, False), (1024, 512, 49, 5, False),
+                                                 (128, 128, 37, 9, True), (320, 128, 196, 300, True)])
+def test_small_launch_conv1x1_is_bit_identical_to_the_tiled_kernel(cin, cout, hw, n, terms):
+    """k_conv1x1_h2s (one wave per 32 x 32 tile, no LDS: the reference's batch sizes, test.py:1513, milvus_retrieval.py:53-66)
+    against k_conv1x1_h2 on the same input: the same bits in every output value, published range and bottleneck scale -- so a
+    row's embedding does not depend on which kernel its batch size selected.  Images of different magnitudes; a poisoned one is
+    NaN from both kernels."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(cin * 7 + hw + n)
+    ctot = cin + 32
+    buf = torch.randn(n, ctot, hw, generator=g, device=dev)
+    buf *= (10.0 ** torch.randint(-3, 3, (n, 1, 1), generator=g, device=dev).float())
+    w = torch.randn(cout, cin, generator=g, device=dev) / cin ** 0.5
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3
+    bias = torch.randn(cout, generator=g, device=dev)
+    w2, osc = _split2h_weights(w)
+    rng_in = buf[:, :cin].abs().amax(dim=(1, 2)).contiguous()
+    if n > 2:
+        rng_in[1] = float("inf")                                       # a poisoned image: NaN bits must agree too
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    outs = []
+    try:
+        for limit in (0, 1 << 20):
+            _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV1X1_SMALL_MAX_WG, limit), "set_tuning")
+            y = torch.full((n, cout, hw), -7.0, device=dev)
+            aux = torch.zeros(n, device=dev)
+            if terms:
+                _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(buf), ctot * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(bias), n, hw,
+                                                                  vp(y), vp(rng_in), float(sc.abs().max()), float(sh.abs().max()),
+                                                                  float(w.abs().sum(dim=1).max()), float(bias.abs().max()), vp(aux),
+                                                                  0, None), "terms")
+            else:
+                _lib.check(lib.mirx_conv1x1_bn_relu_split2h(vp(buf), ctot * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(bias), n, hw, cout,
+                                                            1, vp(y), cout * hw, vp(rng_in), float(sc.abs().max()),
+                                                            float(sh.abs().max()), vp(aux), 0, 0, None), "split2h")
+            torch.cuda.synchronize()
+            outs.append((y.view(torch.int32).clone(), aux.view(torch.int32).clone()))
+    finally:
+        _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV1X1_SMALL_MAX_WG, 128), "set_tuning")
+    clean = [b for b in range(n) if not (n > 2 and b == 1)]
+    assert torch.equal(outs[0][0][clean], outs[1][0][clean])
+    assert torch.equal(outs[0][1][clean], outs[1][1][clean])
+    if n > 2:                                                          # the poisoned image: NaN from both (payload bits are not a contract)
+        for y, aux in outs:
+            # terms: the image's 2^-t is NaN, which is what poisons the 3x3 conv that consumes the (then meaningless) terms
+            assert bool(torch.isnan(aux.view(torch.float32)[1])) if terms else bool(torch.isnan(y[1].view(torch.float32)).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,n", [(56, 1), (28, 3), (14, 5), (14, 1), (7, 9), (7, 1), (14, 130)])
+def test_small_launch_conv3x3_is_bit_identical_to_the_strip_kernel(side, n):
+    """k_conv3x3_d2s (one wave per 32 output pixels, no LDS) against k_conv3x3_d2p on the same pre-split bottleneck: the same
+    bits in every output value and published range."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side * 31 + n)
+    cin, hw = 64, side * side
+    buf = torch.randn(n, cin, hw, generator=g, device=dev)
+    buf *= (10.0 ** torch.randint(-2, 3, (n, 1, 1), generator=g, device=dev).float())
+    w1 = torch.randn(128, cin, generator=g, device=dev) / cin ** 0.5
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3
+    b1 = torch.randn(128, generator=g, device=dev) * 0.2
+    w3 = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    w2, osc = _split2h_weights(w1)
+    c3, c3osc = _conv3x3_weights_split2h(w3, YTERMS_CHANNEL_ORDER)
+    y = torch.empty((n, 128, hw), device=dev)
+    rng = buf.abs().amax(dim=(1, 2)).contiguous()
+    yinv = torch.zeros(n, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                       # noqa: E731
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(buf), cin * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), n, hw, vp(y),
+                                                      vp(rng), float(sc.abs().max()), float(sh.abs().max()),
+                                                      float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv), 0, None), "terms")
+    outs = []
+    try:
+        for limit in (0, 1 << 20):
+            _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, limit), "set_tuning")
+            out = torch.full((n, 40, hw), -3.0, device=dev)
+            orng = torch.zeros(n, device=dev)
+            _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), n, side, vp(out), 40 * hw, vp(yinv), vp(orng), 0, None),
+                       "conv3x3_terms")
+            torch.cuda.synchronize()
+            assert bool((out[:, 32:] == -3.0).all())
+            outs.append((out.view(torch.int32).clone(), orng.view(torch.int32).clone()))
+    finally:
+        _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, 96), "set_tuning")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    y64 = torch.relu(torch.einsum("oc,bcp->bop", w1.double(), torch.relu(buf.double() * sc.double()[None, :, None] + sh.double()[None, :, None]))
+                     + b1.double()[None, :, None]).unflatten(2, (side, side))
+    want = torch.nn.functional.conv2d(y64, w3.double(), None, padding=1).flatten(2)
+    got = outs[1][0].view(torch.float32)[:, :32].double()
+    for b in range(n):
+        assert float((got[b] - want[b]).abs().max()) < 3e-6 * float(want[b].abs().max()), b
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,side,n,pad_in,pad_out", [(256, 28, 3, 16, 28), (512, 14, 2, 28, 0), (256, 56, 1, 0, 16)])
-def test_transition_kernels_with_padded_planes(c, side, n, pad_in, pad_out):
+def test_transition_kernels_with_padded_planes(c, side, n, pad_in, pad_out, conv1x1_kernel):
     """The two launches of a transition on buffers whose channel planes are padded (mirx.model._plane_stride):
     mirx_bn_relu_avgpool2 reads planes `x_plane_stride` apart, mirx_conv1x1_bn_relu_split2h writes planes `y_plane_stride`
     apart; the gaps hold NaN before and after (never read, never written)."""
@@ -528,7 +648,7 @@ def test_a_poisoned_image_leaves_its_batch_mates_unchanged(model_and_sd):
                                                     (14, 1, 1008, 1.0, 0), (14, 3, 512, 1.0, 28), (28, 2, 128, 3.0, 16),
                                                     (56, 1, 96, 1.0, 32), (7, 5, 512, 1.0, 0), (7, 1, 992, 1.0, 0),
                                                     (7, 8, 640, 30.0, 0), (7, 3, 512, 1.0, 15)])
-def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad):
+def test_dense_layer_terms_path_matches_float64(side, batch, cin, mag, pad, conv1x1_kernel):
     """conv1x1 -> pre-split fp16-term bottleneck -> conv3x3 (mirx_conv1x1_bn_relu_split2h_terms +
     mirx_conv3x3_direct_terms_nchw) against a float64 dense layer relu(bn2(conv1(relu(bn1(x))))) -> conv2: 3e-6 of the
     largest output at any input magnitude; the halo ring of the DMA-staged strips is zero (out-of-range buffer loads);

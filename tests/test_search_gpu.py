@@ -225,6 +225,33 @@ def test_adjacent_passing_rows_claim_distinct_candidate_slots(nq):
     assert np.array_equal(o_i[:, 0], (qi * run).numpy())       # the lowest id of the run
 
 
+def test_a_whole_accumulator_tile_of_passing_scores_takes_the_spill_path():
+    """k_gemm16 parks the lanes that hold a passing score in a 64-entry ring per wave; when more of them turn up inside ONE
+    gallery tile the ring moves to the wave's global spill area (round 4).  256 identical queries against 200-row runs of
+    identical rows and a forced mid-range threshold make every score of a 128 x 64 wave tile pass at once (1024 ring
+    entries): nothing may be lost -- stats.candidates is exact and the answer is the oracle's."""
+    from mirx import _lib as L
+    from mirx.index import FlatIndex
+    d, run, nbase, nq = 256, 200, 200, 256                     # 40 000 rows: the MFMA tier (small galleries are scanned exactly)
+    base = _unit(nbase, d, 23)
+    g = base.repeat_interleave(run, dim=0)
+    q = base[torch.zeros(nq, dtype=torch.long)].clone()
+    q[nq // 2:] = base[7]                                      # second half of the queries: another run, another tile
+    ix = FlatIndex(d, "COSINE", 0)
+    ix.add(g)
+    dots = (base @ base.t()).fill_diagonal_(-1)
+    assert float(dots.max()) < 0.45
+    ix.set_option(L.OPT_FORCE_TAU, int(np.float32(0.5).view(np.uint32)))
+    s, i = ix.search(q, 10, return_f64=True)
+    st = ix.last_stats()
+    assert st["candidates"] == nq * run, st
+    assert st["incomplete"] == 0 and st["tier1_answered"] + st["exact_answered"] == nq, st
+    o_s, o_i = OS.topk(q.numpy(), g.numpy(), 10)
+    np.testing.assert_array_equal(i.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+
+
+
 def test_more_than_8192_queries_multi_pass():
     """VERDICT r1 (e): 8192 + 300 queries in one call = two internal passes (8192, then 300 at a different query tile);
     ids, fp64 scores and the aggregated stats must be those of one search (W = 8 ranks hit this path with 32 768 queries)."""
