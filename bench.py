@@ -612,19 +612,40 @@ def main():
     if rank == 0 and not args.search_only:
         # calibration pass OUTSIDE the timed region: HIP events around every launch of the embed stage's dominant
         # hand-written kernel family (the fused 1x1 convolutions of the 58 dense layers and 3 transitions)
-        # (in the configuration the timed steps run: one micro-batch split over the embed streams)
+        # Two passes.  (1) ONE stream, the images one stream of the step embeds: a kernel then has the chip to itself and its
+        # duration is its own -- this is `achieved` (and what the committed one-stream rocprof summary must agree with).
+        # (2) the step's own configuration, the micro-batch split over the embed streams: launches of the two streams overlap,
+        # so a launch's HIP-event duration includes the time it shares the chip -- reported beside it as `in_step`.
+        per_stream = args.embed_batch // (len(side) if side else 1)
+        xcal = pool[0][:per_stream]
+
+        def families():
+            out = {}
+            for ev_a, ev_b, f, nb, kind in model.conv1x1_timer:
+                e = out.setdefault(kind, [0.0, 0.0, 0.0, 0])
+                e[0] += ev_a.elapsed_time(ev_b)
+                e[1] += f
+                e[2] += nb
+                e[3] += 1
+            return out
+
+        in_step = None
+        if side is not None and nmb == 1:
+            model.conv1x1_timer = []
+            with torch.no_grad():
+                embed_all()
+            torch.cuda.synchronize(dev)
+            f2 = families()
+            if f2:
+                _, (ms2, _, nb2, nl2) = max(f2.items(), key=lambda kv: kv[1][0])
+                in_step = {"streams": len(side), "launches": nl2, "sum_of_launch_ms": ms2, "algorithmic_bytes": nb2,
+                           "GBps_over_summed_launch_time": nb2 / (ms2 * 1e-3) / 1e9,
+                           "note": "HIP-event durations of launches that share the chip with the other stream's kernels"}
         model.conv1x1_timer = []
-        xcal = pool[0]
         with torch.no_grad():
-            embed_all() if nmb == 1 else model(xcal)
+            model(xcal)
         torch.cuda.synchronize(dev)
-        fams = {}
-        for a, b, f, nb, kind in model.conv1x1_timer:
-            e = fams.setdefault(kind, [0.0, 0.0, 0.0, 0])
-            e[0] += a.elapsed_time(b)
-            e[1] += f
-            e[2] += nb
-            e[3] += 1
+        fams = families()
         model.conv1x1_timer = None
         if fams:
             # the dominant hand-written family of the embed stage by time (the fused 1x1 convolutions of the 58 dense layers and
@@ -636,11 +657,11 @@ def main():
             embed_roof = {"bound": "hbm",
                           "kernel": ("mirx::k_conv1x1_h2 (fused BN+ReLU+1x1 conv+BN+ReLU, two fp16 MFMA terms, fp32-grade), "
                                      if kind == "conv1x1" else "mirx::k_dense_fused (one-launch dense layer, bottleneck in LDS), ")
-                                    + f"{nl} launches of one {b}-image forward on {len(side) if side and nmb == 1 else 1} stream(s)",
+                                    + f"{nl} launches of one {b}-image forward on one stream",
                           "dtype": "f32 (2 x fp16 terms)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
                           "algorithmic_bytes_per_forward": nbytes, "ms_per_forward": ms,
                           "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
-                          "traffic": None if tr is None else tr * b, "traffic_profile": tr_file}
+                          "traffic": None if tr is None else tr * b, "traffic_profile": tr_file, "in_step": in_step}
     if rank == 0:
         dimp = (args.dim + 63) // 64 * 64
         flop = 2.0 * (world * q_local // max(1, args.search_chunks if world > 1 else 1)) * (hi - lo) * dimp

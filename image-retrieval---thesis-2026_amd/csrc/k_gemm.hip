@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // operand with a v_max_f32 x, x: four more instructions per tile in the fused check's issue budget)
 #define MIRX_TILEMAX(T) vmax2(vmax3((T)[0], (T)[1], (T)[2]), (T)[3])
 
-    auto epilogue = [&](int64_t gt_) __attribute__((always_inline)) {
+    auto epilogue = [&](int64_t gt_, int n_first) __attribute__((always_inline)) {
         int el = lane;
         asm volatile("" : "+v"(el));
         const int quad = el >> 4, col = el & 15;
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         } else {
 #pragma unroll
             for (int n0 = 0; n0 < N_REP; n0 += 2) {
+                if (n0 < n_first) continue;
                 // maxima per row tile first: the candidate path then looks only inside row tiles that
                 // hold a passing score (about two scores per wave and gallery tile pass, out of 2048)
                 float mr0[M_REP], mr1[M_REP];
@@ -661,22 +662,51 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     // Z = 1: the first slice of a gallery tile starts its 32 accumulator tiles from the constant 0 (no
     // 128 v_mov per tile)
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    // with FUSE, Z = 1 also means: test the previous gallery tile's values of the two accumulator tiles first
+    // FUSE: where the threshold tests of a gallery tile's 32 accumulator tiles sit.  A SITE tests one tile pair (row tile mi,
+    // query tiles n0 and n0 + 1): 4 VALU for the two maxima and two ballots against the two thresholds.  The sites of query
+    // tiles 0,1 ride in the LAST K-tile's last H2 (L = 1: those tiles are final once its H1 has run, and nothing writes them
+    // before the next gallery tile's first H1); the sites of query tiles 2,3 ride in the NEXT gallery tile's first H1 (Z = 1,
+    // which writes only query tiles 0,1).  Inside its phase a tested tile pair is therefore NOT overwritten, so the branch on a
+    // site's ballots is taken ONE SITE LATER (MIRX_TEST_PREV): the chain max -> compare -> SGPR -> scalar OR -> branch parks an
+    // in-order wave for ~90 cycles when the branch follows the compare directly (measured: 87 cycles per site, both waves of a
+    // SIMD doing the same), and costs an issue slot when the next site's maxima and MFMAs sit in between.  Variants measured
+    // and dropped: all sixteen sites in one K-tile (it stretched from 2 400 to 4 150 cycles before a single score passed);
+    // branch-free sites that record a bit per site and one flush per phase (the bookkeeping is the same SGPR round trip per
+    // site); running maxima per phase or per group of row tiles with one flush that re-visits the sites (cheap sites, but the
+    // re-visit runs in two phases of three on the slowest of eight waves: 6.2 vs 5.9 ms per launch).
     float ftau[N_REP] = {0.0f, 0.0f, 0.0f, 0.0f};
     int64_t gt_prev = 0;
-#define MIRX_CHECK2(MI, N0)                                                                                      \
+    unsigned long long pend_a = 0, pend_b = 0;     // ballots of the previous site of the phase (wave-uniform)
+#define MIRX_SITE_TEST(GT, MI, N0)                                                                               \
+    if (__builtin_expect((pend_a | pend_b) != 0, 0)) {                                                           \
+        const bool hit_ = (MIRX_TILEMAX(acc[MI][N0]) > ftau[N0]) | (MIRX_TILEMAX(acc[MI][(N0) + 1]) > ftau[(N0) + 1]); \
+        emit_pair(GT, MI, N0, acc[MI][N0], acc[MI][(N0) + 1], hit_, pend_a | pend_b);                            \
+    }
+    // site MI: its maxima and ballots; then the test of site MI - 1 (whose ballots are a site old by now)
+#define MIRX_CHECK2(GT, MI, N0)                                                                                  \
     {                                                                                                            \
         const float m0_ = MIRX_TILEMAX(acc[MI][N0]);                                                             \
         const float m1_ = MIRX_TILEMAX(acc[MI][(N0) + 1]);                                                       \
-        const bool hit_ = (m0_ > ftau[N0]) | (m1_ > ftau[(N0) + 1]);                                             \
-        const unsigned long long bm_ = __ballot(hit_);                                                           \
-        if (__builtin_expect(bm_ != 0, 0)) emit_pair(gt_prev, MI, N0, acc[MI][N0], acc[MI][(N0) + 1], hit_, bm_); \
+        const unsigned long long na_ = __ballot(m0_ > ftau[N0]), nb_ = __ballot(m1_ > ftau[(N0) + 1]);           \
+        if constexpr ((MI) > 0) MIRX_SITE_TEST(GT, (MI) - 1, N0)                                                 \
+        pend_a = na_;                                                                                            \
+        pend_b = nb_;                                                                                            \
+    }
+    // the phase's last site (row tile 7) is tested behind the phase
+#define MIRX_FLUSH_HITS(GT, N0)                                                                                  \
+    {                                                                                                            \
+        MIRX_SITE_TEST(GT, M_REP - 1, N0)                                                                        \
+        pend_a = pend_b = 0;                                                                                     \
     }
 #define MIRX_MFMA2Z(MI, N0, Z)                                                                         \
-    if constexpr ((Z) && FUSE) MIRX_CHECK2(MI, N0)                                                     \
+    if constexpr ((Z) && FUSE && (N0) == 0) MIRX_CHECK2(gt_prev, MI, 2)                                \
     acc[MI][N0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0], (Z) ? zero4 : acc[MI][N0], 0, 0, 0); \
     acc[MI][N0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[MI], fb[N0 + 1], (Z) ? zero4 : acc[MI][N0 + 1], 0, 0, 0);
 #define MIRX_MFMA2(MI, N0) MIRX_MFMA2Z(MI, N0, 0)
+    // L = 1 (last K-tile of a gallery tile, its last H2): query tiles 0,1 of row tile MI are final -- test them here
+#define MIRX_MFMA2L(MI, L)                                                                             \
+    if constexpr ((L) && FUSE) MIRX_CHECK2(gt, MI, 0)                                                  \
+    MIRX_MFMA2Z(MI, 2, 0)
     // ---- LDS-DMA of the K-tile after next, one 1-KiB piece at a time --------------------------------
     // A wave's issue stalls for 60-180 cycles on every `buffer_load ... lds` piece, and right after the
     // workgroup barrier all eight waves would stall together while the MFMA pipes drain.  So the eight
@@ -748,7 +778,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     fa[MI - 1] = MIRX_LDA(NS, NCUR, MI - 1);              \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#define MIRX_H2_ROW(MI, NCUR, NS) MIRX_H2_ROWZ(MI, NCUR, NS, 0)
+#define MIRX_H2_ROWL(MI, NCUR, NS, L)                     \
+    MIRX_MFMA2L(MI, L)                                    \
+    fa[MI - 1] = MIRX_LDA(NS, NCUR, MI - 1);              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     // H2 of a slice (query tiles 2,3) without DMA slots
 #define MIRX_H2(NCUR, NS, Z)                              \
     MIRX_MFMA2Z(0, 2, Z)                                  \
@@ -767,24 +801,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     // H2 of a K-tile's last slice: reads the next K-tile's first fragments and carries eight DMA slots
-#define MIRX_H2_DMA(NCUR, NS)                             \
-    MIRX_MFMA2(0, 2)                                      \
+#define MIRX_H2_DMA(NCUR, NS, L)                          \
+    MIRX_MFMA2L(0, L)                                     \
     MIRX_SLOT_A(0, 2)                                     \
-    MIRX_H2_ROW(1, NCUR, NS)                              \
+    MIRX_H2_ROWL(1, NCUR, NS, L)                          \
     MIRX_SLOT_A(1, 2)                                     \
-    MIRX_H2_ROW(2, NCUR, NS)                              \
+    MIRX_H2_ROWL(2, NCUR, NS, L)                          \
     fb[0] = MIRX_LDB(NS, NCUR, 0);                        \
     MIRX_SLOT_A(0, 3)                                     \
-    MIRX_H2_ROW(3, NCUR, NS)                              \
+    MIRX_H2_ROWL(3, NCUR, NS, L)                          \
     MIRX_SLOT_A(1, 3)                                     \
-    MIRX_H2_ROW(4, NCUR, NS)                              \
+    MIRX_H2_ROWL(4, NCUR, NS, L)                          \
     fb[1] = MIRX_LDB(NS, NCUR, 1);                        \
     MIRX_SLOT_B(0, 0)                                     \
-    MIRX_H2_ROW(5, NCUR, NS)                              \
+    MIRX_H2_ROWL(5, NCUR, NS, L)                          \
     MIRX_SLOT_B(1, 0)                                     \
-    MIRX_H2_ROW(6, NCUR, NS)                              \
+    MIRX_H2_ROWL(6, NCUR, NS, L)                          \
     MIRX_SLOT_B(0, 1)                                     \
-    MIRX_H2_ROW(7, NCUR, NS)                              \
+    MIRX_H2_ROWL(7, NCUR, NS, L)                          \
     fa[7] = MIRX_LDA(NS, NCUR, 7);                        \
     MIRX_SLOT_B(1, 1)
     // one K-tile (held in buffer `cur`):
@@ -792,7 +826,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     //   slice 1: H1 | barrier: buffer `cur` is free, the other buffer's DMA has landed | H2 with DMA slots,
     //            reading the first fragments of the next K-tile from the other buffer.
     // No branch encloses an MFMA (see k_gemm).
-#define MIRX_KTILE(KT, Z)                                                                          \
+#ifdef MIRX_EXP_CYCLES
+#define MIRX_SEG(Z, I)                                                       \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        seg_sum[(Z) ? 0 : 1][I] += now_ - seg_t;                             \
+        seg_t = now_;                                                        \
+    }
+#else
+#define MIRX_SEG(Z, I)
+#endif
+#define MIRX_KTILE(KT, Z, L)                                                                       \
+    MIRX_SEG(Z, 0)                                                                                 \
     MIRX_H1_HEAD(0, 0, Z)                                                                          \
     MIRX_SLOT_B(0, 2)                                                                              \
     MIRX_MFMA2Z(1, 0, Z)                                                                           \
@@ -803,11 +848,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     MIRX_SLOT_B(1, 3)                                                                              \
     MIRX_MFMA2Z(4, 0, Z) MIRX_MFMA2Z(5, 0, Z) MIRX_MFMA2Z(6, 0, Z) MIRX_MFMA2Z(7, 0, Z)            \
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
+    MIRX_SEG(Z, 1)                                                                                 \
+    if constexpr ((Z) && FUSE) MIRX_FLUSH_HITS(gt_prev, 2)                                         \
     MIRX_H2(0, 1, Z)                                                                               \
+    MIRX_SEG(Z, 2)                                                                                 \
     MIRX_H1_HEAD(0, 1, 0)                                                                          \
     MIRX_MFMA2(1, 0) MIRX_MFMA2(2, 0) MIRX_MFMA2(3, 0) MIRX_MFMA2(4, 0)                            \
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                             \
+    MIRX_SEG(Z, 3)                                                                                 \
     MIRX_KBARRIER(); /* last reads of `cur` returned; the other buffer's DMA (mine) landed */      \
+    MIRX_SEG(Z, 4)                                                                                 \
     MIRX_DMA_AT_BARRIER(KT)                                                                        \
     MIRX_SLOT_A(0, 0)                                                                              \
     MIRX_MFMA2(5, 0)                                                                               \
@@ -816,7 +866,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     MIRX_SLOT_A(0, 1)                                                                              \
     MIRX_MFMA2(7, 0)                                                                               \
     MIRX_SLOT_A(1, 1)                                                                              \
-    MIRX_H2_DMA(1, 0)                                                                              \
+    MIRX_H2_DMA(1, 0, L)                                                                           \
+    if constexpr ((L) && FUSE) MIRX_FLUSH_HITS(gt, 0)                                              \
+    MIRX_SEG(Z, 5)                                                                                 \
     acur ^= 32768;                                                                                 \
     bcur ^= 32768;                                                                                 \
     cur ^= 1;
@@ -841,8 +893,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     dma_a = smem + A_TILE_BYTES + wave * 1024;
     dma_b = smem + LDS_B0 + B_TILE_BYTES + wave * 1024;
 #ifdef MIRX_EXP_CYCLES
-    unsigned long long cy_sum = 0, cy_n = 0, ep_sum = 0, ep_n = 0;
+    unsigned long long cy_sum = 0, cy_n = 0, ep_sum = 0, ep_n = 0, k0_sum = 0, seg_sum[2][6] = {}, seg_t = 0;
     const unsigned long long life0 = __builtin_amdgcn_s_memtime();
+    seg_t = life0;
 #endif
     // Waves 4-7 are the younger SIMD partners and lose every issue arbitration against waves 0-3, which
     // then wait for them at each barrier: a static priority for the younger half evens the two out
@@ -850,6 +903,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
     if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 
     if constexpr (FUSE) {
+        // this lane's four thresholds: constant for the workgroup's life (read once: a read per gallery tile waited for the
+        // twelve fragment reads queued in front of it, ~500 cycles)
+#pragma unroll
+        for (int ni = 0; ni < N_REP; ++ni) ftau[ni] = ltau[wn * 64 + ni * 16 + (lane & 15)];
         // nothing of "the tile before the first" passes a threshold
         const f32x4 ninf4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -870,15 +927,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
             // (never on the bench workload: a tile parks ~2 entries per wave; the area holds 2048)
             if (__builtin_expect(scnt > SPILL_SLOTS - SPILL_PER_TILE, 0)) drain();
         }
-        if constexpr (FUSE) {
-#pragma unroll
-            for (int ni = 0; ni < N_REP; ++ni) ftau[ni] = ltau[wn * 64 + ni * 16 + (lane & 15)];
-        }
-        MIRX_KTILE(0, 1)                               // the first slice initialises the accumulators
+        MIRX_KTILE(0, 1, 0)                            // the first slice initialises the accumulators
+#ifdef MIRX_EXP_CYCLES
+        k0_sum += __builtin_amdgcn_s_memtime() - cy0;
+#endif
 #pragma unroll 1
-        for (int kt = 1; kt < nk; ++kt) {
-            MIRX_KTILE(kt, 0)
+        for (int kt = 1; kt < nk - 1; ++kt) {
+            MIRX_KTILE(kt, 0, 0)
         }
+        MIRX_KTILE(nk - 1, 0, 1)                       // nk >= 2: the last K-tile is never the first
 #ifdef MIRX_EXP_CYCLES
         cy_sum += __builtin_amdgcn_s_memtime() - cy0;
         cy_n += nk;
@@ -887,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
 #ifdef MIRX_EXP_CYCLES
         const unsigned long long ep0 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (!FUSE) epilogue(gt);
+        if constexpr (!FUSE) epilogue(gt, 0);
 #ifdef MIRX_EXP_CYCLES
         ep_sum += __builtin_amdgcn_s_memtime() - ep0;
         ep_n += 1;
@@ -897,12 +954,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         gt = gt_nx;
         rsrc_a = rsrc_a_nx;
     }
-    if constexpr (FUSE) epilogue(gt);                  // the last gallery tile of this workgroup
+    if constexpr (FUSE) epilogue(gt, 2);               // the last gallery tile of this workgroup: its query tiles 2,3 are still untested
 #ifdef MIRX_EXP_CYCLES
     if (lane == 0 && (blockIdx.x % 61) == 0 && cy_n > 1000 && (wave == 0 || wave == 4))
-        printf("wg %d wave %d: %.0f cycles per K-tile in the K loop (%llu K-tiles); epilogue %.0f cycles per gallery tile; kernel %.0f cycles per K-tile\n",
-               (int)blockIdx.x, wave, (double)cy_sum / cy_n, cy_n, (double)ep_sum / ep_n,
-               (double)(__builtin_amdgcn_s_memtime() - life0) / cy_n);
+        printf("wg %d wave %d segments (loop top/prev end -> H1(s0) start | H1(s0) | H2(s0) | H1(s1) to barrier | barrier wait | rest): first K-tile %.0f %.0f %.0f %.0f %.0f %.0f ; other K-tiles %.0f %.0f %.0f %.0f %.0f %.0f\n",
+               (int)blockIdx.x, wave, (double)seg_sum[0][0] / ep_n, (double)seg_sum[0][1] / ep_n, (double)seg_sum[0][2] / ep_n,
+               (double)seg_sum[0][3] / ep_n, (double)seg_sum[0][4] / ep_n, (double)seg_sum[0][5] / ep_n,
+               (double)seg_sum[1][0] / (cy_n - ep_n), (double)seg_sum[1][1] / (cy_n - ep_n), (double)seg_sum[1][2] / (cy_n - ep_n),
+               (double)seg_sum[1][3] / (cy_n - ep_n), (double)seg_sum[1][4] / (cy_n - ep_n), (double)seg_sum[1][5] / (cy_n - ep_n));
+    if (lane == 0 && (blockIdx.x % 61) == 0 && cy_n > 1000 && (wave == 0 || wave == 4))
+        printf("wg %d wave %d: %.0f cycles per K-tile in the K loop (%llu K-tiles); first K-tile of a gallery tile (with the fused checks) %.0f, the others %.0f; kernel %.0f cycles per K-tile\n",
+               (int)blockIdx.x, wave, (double)cy_sum / cy_n, cy_n, (double)k0_sum / ep_n,
+               (double)(cy_sum - k0_sum) / (cy_n - ep_n), (double)(__builtin_amdgcn_s_memtime() - life0) / cy_n);
 #endif
     if (MODE == 0) {
         drain();
@@ -913,16 +976,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm16(GemmArgs A) {
         }
     }
 #undef MIRX_KTILE
+#undef MIRX_SEG
 #undef MIRX_H1_HEAD
 #undef MIRX_H2
 #undef MIRX_H2_DMA
 #undef MIRX_SLOT_A
 #undef MIRX_SLOT_B
 #undef MIRX_DMA_AT_BARRIER
-#undef MIRX_H2_ROW
+#undef MIRX_H2_ROWL
+#undef MIRX_MFMA2L
 #undef MIRX_MFMA2
 #undef MIRX_MFMA2Z
 #undef MIRX_CHECK2
+#undef MIRX_SITE_TEST
+#undef MIRX_FLUSH_HITS
 #undef MIRX_TILEMAX
 #undef MIRX_H2_ROWZ
 #undef MIRX_LDA

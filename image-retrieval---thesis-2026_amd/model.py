@@ -856,6 +856,7 @@ _TENSOR_VERSION = operator.attrgetter("_version")
 
 class DenseNet121(_Configurable, nn.Module):
     """Reference model.py:42-84, MI355X-native inference path."""
+    accepts_uint8 = True        # forward() takes raw 8-bit images and applies ToTensor + Normalize itself (input_mean / input_std)
 
     def __init__(self, pretrained=False, embedding_dim=None, num_labels=None, weights=None):
         super().__init__()

@@ -238,7 +238,8 @@ def default_transform(img_size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, resize
     mean = np.asarray(mean, dtype=np.float32).reshape(3, 1, 1)
     std = np.asarray(std, dtype=np.float32).reshape(3, 1, 1)
 
-    def tf(img):
+    def pixels(img):
+        """convert -> Resize -> CenterCrop: the 8-bit pixels [3, S, S] that ToTensor + Normalize would then turn into floats"""
         from PIL import Image
         img = img.convert("RGB")
         w, h = img.size
@@ -249,9 +250,17 @@ def default_transform(img_size=224, mean=IMAGENET_MEAN, std=IMAGENET_STD, resize
         img = img.resize((nw, nh), Image.BILINEAR)
         left, top = int(round((nw - img_size) / 2.0)), int(round((nh - img_size) / 2.0))
         img = img.crop((left, top, left + img_size, top + img_size))
-        x = np.asarray(img, dtype=np.uint8).transpose(2, 0, 1).astype(np.float32) / np.float32(255.0)
+        return np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))
+
+    def tf(img):
+        x = pixels(img).astype(np.float32) / np.float32(255.0)
         return torch.from_numpy(np.ascontiguousarray((x - mean) / std))
 
+    # MilvusRetriever.search hands the 8-bit pixels to a model that normalises them itself with the same constants (DenseNet121:
+    # inside the stem kernel, bit-identical to the float path -- tests/test_model_gpu.py): a quarter of the bytes to the device
+    # and no float pass over the image on the host
+    tf.pixels = pixels
+    tf.mean, tf.std = tuple(float(v) for v in mean.ravel()), tuple(float(v) for v in std.ravel())
     return tf
 
 
@@ -279,6 +288,17 @@ class MilvusRetriever:
         except StopIteration:
             return torch.device("cuda")
 
+    def _query_tensor(self, img):
+        """transform(img)[None] -- or, when the transform is default_transform and the model normalises 8-bit input itself with
+        the transform's constants, the 8-bit pixels (same embedding bit for bit, a quarter of the bytes, no host float pass)."""
+        tf, m = self.transform, self.model
+        px = getattr(tf, "pixels", None)
+        if px is not None and getattr(m, "accepts_uint8", False) and self._device().type == "cuda" and not m.training:
+            mean, std = getattr(m, "input_mean", None), getattr(m, "input_std", None)
+            if mean is not None and tuple(float(v) for v in mean) == tf.mean and tuple(float(v) for v in std) == tf.std:
+                return torch.from_numpy(px(img)).unsqueeze(0)
+        return tf(img).unsqueeze(0)
+
     def embed(self, images):
         """Batched F.normalize(model(x)) for a [B,3,H,W] tensor (milvus_retrieval.py:60-63)."""
         with torch.no_grad():
@@ -295,7 +315,7 @@ class MilvusRetriever:
             img = Image.open(query_image_path).convert("RGB")
         else:
             img = query_image_path
-        query_embedding = self.embed(self.transform(img).unsqueeze(0))
+        query_embedding = self.embed(self._query_tensor(img))
         if self.collection is None:
             self.load_collection()
         if metric_type not in ("COSINE", "IP", "L2"):

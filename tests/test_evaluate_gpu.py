@@ -126,6 +126,35 @@ def test_retriever_protocol(tmp_path):
     mgr.disconnect()
 
 
+def test_single_query_search_hands_8bit_pixels_to_a_model_that_normalises_them(tmp_path):
+    """milvus_retrieval.py:53-66 embeds ONE image per call.  With default_transform and a DenseNet121 (which applies ToTensor +
+    Normalize inside its stem kernel) MilvusRetriever.search sends the 8-bit pixels: the query embedding must be the float
+    path's, bit for bit; a transform with other constants, or another model, keeps the float path."""
+    from PIL import Image
+    from mirx.model import DenseNet121
+    from mirx.retriever import MilvusManager, MilvusRetriever, SIGLIP_MEAN, SIGLIP_STD, default_transform
+    torch.manual_seed(0)
+    m = DenseNet121().eval().cuda()
+    mgr = MilvusManager(dataset="covid")
+    mgr.connect()
+    mgr.create_collection("densenet121", drop_old=True)
+    col = mgr.collections["densenet121"]
+    g = torch.nn.functional.normalize(torch.randn(300, 1024, generator=torch.Generator().manual_seed(5)), dim=1)
+    col.insert([[f"/d/{i}.png" for i in range(300)], ["normal"] * 300, g])
+    img = Image.fromarray((np.random.default_rng(1).random((280, 320, 3)) * 255).astype(np.uint8))
+    tf = default_transform(224)
+    r = MilvusRetriever(mgr, "densenet121", m, tf)
+    assert r._query_tensor(img).dtype == torch.uint8
+    res, qemb = r.search(img, top_k=5)
+    want = r.embed(tf(img).unsqueeze(0))
+    assert torch.equal(qemb, want)
+    res2, _ = MilvusRetriever(mgr, "densenet121", m, lambda im: tf(im)).search(img, top_k=5)     # a plain callable: float path
+    assert [d["id"] for d in res] == [d["id"] for d in res2]
+    other = default_transform(224, SIGLIP_MEAN, SIGLIP_STD)
+    assert MilvusRetriever(mgr, "densenet121", m, other)._query_tensor(img).dtype == torch.float32
+    mgr.disconnect()
+
+
 def test_search_by_embeddings_reference_signature():
     """retrieval_analysis/milvus_adapter.py:218-275: (queries, query_embeddings, top_k, search_params, reranker,
     exclude_self, metadata_fields, batch_size) -> list[SearchResult]; self dropped by image_path after fetching

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Fabric-side traffic of the dominant kernels (run on the GPU box): separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
-# never combined with a trace), summarised by tools/pmc_traffic.py into gpurun_out/r03_pmc_traffic.json -- copy that to
+# never combined with a trace), summarised by tools/pmc_traffic.py into gpurun_out/${R:-r04}_pmc_traffic.json -- copy that to
 # profiles/.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts half the bytes of wide coalesced loads on gfx950.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # tag counter command...
@@ -14,5 +14,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   run dinov2 $ctr python tools/bench_embed.py --model dinov2 --batch 32 --size 518 --iters 1 --warmup 1
   run medsiglip $ctr python tools/bench_embed.py --model medsiglip --batch 16 --size 448 --iters 1 --warmup 1
 done
-python tools/pmc_traffic.py > gpurun_out/r03_pmc_traffic.json
-cat gpurun_out/r03_pmc_traffic.json
+python tools/pmc_traffic.py > gpurun_out/${R:-r04}_pmc_traffic.json
+cat gpurun_out/${R:-r04}_pmc_traffic.json

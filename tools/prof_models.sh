@@ -6,7 +6,7 @@ for spec in "convnextv2 64 384" "dinov2 32 518" "medsiglip 16 448"; do
   set -- $spec
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$1 -- python tools/bench_embed.py --model $1 --batch $2 --size $3 --iters 5 > gpurun_out/prof_$1.log 2>&1
   f=$(find gpurun_out/prof_$1 -name "*kernel_stats.csv" | head -1)
-  cp "$f" gpurun_out/r03_$1_kernel_stats.csv
+  cp "$f" gpurun_out/${R:-r04}_$1_kernel_stats.csv
   tail -1 gpurun_out/prof_$1.log
   python - "$f" <<'PY'
 import csv, sys
