@@ -543,7 +543,7 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     if (yterms && px >= ((int64_t)1 << 27)) return hipErrorInvalidValue;     // ... and the 32-byte records of y (16 per pixel) too
     // small launches (the reference's own batch sizes): one wave per 32 x 32 tile, no LDS (k_conv1x1_h2s.hip) -- when this
     // kernel's 128 x 128 tiles would leave most CUs without a workgroup
-    if (px * (cout / CM) < (int64_t)CP * conv1x1_small_max_wg())
+    if (px * (cout / CM) < (int64_t)CP * conv1x1_small_max_wg() && (cin <= 1024 || !scale))
         return launch_conv1x1_h2_small(x, xbs, cin, scale, shift, w2, oscale, bias, n, hw, cout, relu_out, y, ybs, in_amax,
                                        in_ks, in_kb, out_amax, y_ks, y_kb, y_inv_out, xps, yps, st);
     const int npt = px >= (int64_t)2 * CP * MIRX_C1H2_MIN_WG ? MIRX_C1H2_NPT : 1;
@@ -558,12 +558,11 @@ hipError_t launch_conv1x1_h2(const float *x, int64_t xbs, int cin, const float *
     }
 #define MIRX_H2KT(P, R, T, N, TB)                                                                          \
     {                                                                                                      \
-        static bool attr_set = false;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
-        if (!attr_set) {                                                                                   \
+        static unsigned long long attr_devs = 0;      /* per instantiation: the attribute call costs a host microsecond per launch */ \
+        if (first_use_on_device(attr_devs)) {                                                                                   \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1x1_h2<P, R, T, N, TB>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * PLANE_A + N * 2 * PLANE_B)); \
             if (e != hipSuccess) return e;                                                                 \
-            attr_set = true;                                                                               \
         }                                                                                                  \
         hipLaunchKernelGGL((k_conv1x1_h2<P, R, T, N, TB>), grid, dim3(256), lds, st, x, xbs, cin, scale, shift, w2, oscale, bias, \
                            n, hw, cout, y, ybs, in_amax, in_ks, in_kb, oa, y_ks, y_kb, y_inv_out, xps, yps); \

@@ -257,12 +257,11 @@ hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscal
     constexpr int NP = (IPW * (R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
     static_assert((size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2 <= 160 * 1024, "LDS of one CU");
-    static bool attr_set = false;          // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;          // per instantiation
+    if (first_use_on_device(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_d2p<W, R, IPW, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW, NW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(64 * NW), lds,
                        st, yt, w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);

@@ -715,23 +715,15 @@ hipError_t launch_dense_fused(float *buf, int64_t bs, int cin, const float *scal
                               int side, float *range_row, float in_ks, float in_kb, float y_ks, float y_kb, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if ((side != 14 && side != 7) || cin % 32 || cin < DP * KC || cin > MAX_CIN) return hipErrorInvalidValue;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-    }
+    const int n_cu = current_device_cus();
     unsigned *rr = reinterpret_cast<unsigned *>(range_row);
 #define MIRX_DF_LAUNCH(WW)                                                                                        \
     {                                                                                                             \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
+        static unsigned long long attr_devs = 0;                                                                             \
+        if (first_use_on_device(attr_devs)) {                                                                                          \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_fused<WW>),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);            \
             if (e != hipSuccess) return e;                                                                        \
-            attr_set = true;                                                                                      \
         }                                                                                                         \
         const int64_t units = (n + (196 / (WW * WW)) - 1) / (196 / (WW * WW));                                    \
         const unsigned grid = (unsigned)(units < n_cu ? units : n_cu);      /* one persistent workgroup per CU */ \

@@ -1006,15 +1006,7 @@ bool use_mfma16() {
     return v == 1;
 }
 
-int device_cus() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        ncu = v > 0 ? v : 256;
-    }
-    return ncu;
-}
+int device_cus() { return current_device_cus(); }
 
 template <int BN, int MODE>
 hipError_t launch_bn(const GemmArgs &a0, hipStream_t st) {

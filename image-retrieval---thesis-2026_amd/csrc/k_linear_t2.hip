@@ -543,15 +543,7 @@ static void lt2_plan(int64_t tiles, int stages, int cus, int64_t *plain, int64_t
     *parts = (int)g;
 }
 
-static int lt2_cus() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        ncu = v > 0 ? v : 256;
-    }
-    return ncu;
-}
+static int lt2_cus() { return current_device_cus(); }
 
 size_t linear_t2_workspace_bytes(int64_t m, int k, int n) {
     if (m <= 0 || k < 1 || n < 1) return 0;
@@ -585,12 +577,11 @@ hipError_t launch_linear_t2(const void *xt, int64_t m, int k, const void *wt, co
     float *ws = reinterpret_cast<float *>(workspace);
 #define MIRX_T2(A, R, T)                                                                                               \
     {                                                                                                                  \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
+        static unsigned long long attr_devs = 0;                                                                                  \
+        if (first_use_on_device(attr_devs)) {                                                                                               \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_linear_t2<A, R, T>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                 \
             if (e != hipSuccess) return e;                                                                             \
-            attr_set = true;                                                                                           \
         }                                                                                                              \
         hipLaunchKernelGGL((k_linear_t2<A, R, T>), grid, dim3(512), LDS_BYTES, st, reinterpret_cast<const char *>(xt), m, kp, \
                            reinterpret_cast<const char *>(wt), bias, n, res, gamma, out_scale, y,                      \

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_l2_normalize(float *__restrict__ x, int
 
 // One workgroup per image.  Pass 1: one wave per channel sums relu(x*scale+shift) over the
 // hw contiguous pixels (coalesced, shuffle reduce).  Pass 2: L2-normalise the c means.
-__global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
+constexpr int HEAD_THREADS = 1024;     // 16 waves: at one workgroup per image the channel loop is the launch's latency (B = 64: 144 -> ~40 us)
+__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ x,
                                               const float *__restrict__ scale,
                                               const float *__restrict__ shift, int c, int hw,
                                               int normalize, float *__restrict__ y) {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
     // 256 dependent L2 round trips here: 120 us of its 2.4 ms).  relu as a compare: a NaN stays a NaN (fmaxf would drop it and
     // a poisoned image would come out as a finite embedding).
     constexpr int UC = 8;
-    for (int ch0 = wave * UC; ch0 < c; ch0 += 4 * UC) {
+    for (int ch0 = wave * UC; ch0 < c; ch0 += (HEAD_THREADS / WAVE) * UC) {
         float acc[UC];
 #pragma unroll
         for (int u = 0; u < UC; ++u) {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
     }
     const int cpad = (c + 3) & ~3;
     double *nrm_s = reinterpret_cast<double *>(mean_s + cpad);
-    for (int i = c + threadIdx.x; i < cpad; i += 256) mean_s[i] = 0.0f;
+    for (int i = c + threadIdx.x; i < cpad; i += HEAD_THREADS) mean_s[i] = 0.0f;
     __syncthreads();
     if (normalize) {
         if (wave == 0) {
@@ -146,9 +147,9 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ x,
         }
         __syncthreads();
         const double nrm = *nrm_s;
-        for (int i = threadIdx.x; i < c; i += 256) y[b * c + i] = (float)((double)mean_s[i] / nrm);
+        for (int i = threadIdx.x; i < c; i += HEAD_THREADS) y[b * c + i] = (float)((double)mean_s[i] / nrm);
     } else {
-        for (int i = threadIdx.x; i < c; i += 256) y[b * c + i] = mean_s[i];
+        for (int i = threadIdx.x; i < c; i += HEAD_THREADS) y[b * c + i] = mean_s[i];
     }
 }
 
@@ -280,7 +281,7 @@ hipError_t launch_bn_relu_gap_l2norm(const float *x, const float *scale, const f
                                      hipStream_t st) {
     if (n <= 0) return hipSuccess;
     const size_t lds = (size_t)((c + 3) & ~3) * sizeof(float) + 16;
-    hipLaunchKernelGGL(k_head, dim3((unsigned)n), dim3(256), lds, st, x, scale, shift, c, hw,
+    hipLaunchKernelGGL(k_head, dim3((unsigned)n), dim3(HEAD_THREADS), lds, st, x, scale, shift, c, hw,
                        normalize, y);
     return hipGetLastError();
 }

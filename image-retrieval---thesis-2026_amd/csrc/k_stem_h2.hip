@@ -283,12 +283,11 @@ static hipError_t launch_stem_h2_t(const TIN *x, const uint16_t *w2, const float
     const int ph = h / 4, pw = wd / 4;
     const int tiles = ((ph + PTH - 1) / PTH) * ((pw + PTW - 1) / PTW);
     const size_t lds = LDS_BYTES;
-    static bool attr_set = false;           // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_devs = 0;           // per instantiation
+    if (first_use_on_device(attr_devs)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stem_h2<TIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_stem_h2<TIN>, dim3((unsigned)tiles, (unsigned)n, 1), dim3(256), lds, st, x, w2, oscale, scale, shift,
                        h, wd, y, y_bs, in_range, reinterpret_cast<unsigned *>(out_range), mean, stdv);

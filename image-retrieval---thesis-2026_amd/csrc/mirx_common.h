@@ -63,6 +63,28 @@ __host__ __device__ inline bool hit_before(double sa, int64_t ia, double sb, int
     return sa > sb || (sa == sb && ia < ib);
 }
 
+// CUs of the CURRENT device, cached per device (a process that drives several GPUs sizes every persistent grid for the one it
+// launches on: ADVICE r3)
+inline int current_device_cus() {
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cache[dev] == 0) {
+        int v = 256;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        cache[dev] = v > 0 ? v : 256;
+    }
+    return cache[dev];
+}
+// "has this launcher's function attribute been set on the current device": one bit per device in a per-call-site mask
+inline bool first_use_on_device(unsigned long long &mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // unknown: set the attribute again (cheap)
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 #ifdef __HIPCC__
 // ---- device helpers -------------------------------------------------------------------
 __device__ inline int lane_id() { return threadIdx.x & 63; }

@@ -124,6 +124,12 @@ def set_kernel_config(module, cfg):
     assert isinstance(cfg, KernelConfig)
     for m in module.modules():
         m.__dict__["_mirx_cfg"] = cfg
+        # the duck-typed Linear views that are not nn.Modules (a patch-embedding / downsample conv seen as a Linear, SigLIP's
+        # packed q / k / v rows): they run under their owner's configuration too
+        for key in ("_mirx_as_linear", "_mirx_as_linear_cl", "_packed"):
+            view = m.__dict__.get(key)
+            if view is not None:
+                view.__dict__["_mirx_cfg"] = cfg
 
 
 class _Configurable:
@@ -765,8 +771,8 @@ def _layernorm(ln, x, tokens_per_image=0):
     """nn.LayerNorm over the last axis: [HIP] mirx_layernorm for CUDA fp32 inference, F.layer_norm otherwise.
     tokens_per_image > 0: x is [images * tpi, c] and the result comes back channels-first [images, c, tpi]."""
     c = ln.normalized_shape[-1]
-    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c % 4 == 0
-            and len(ln.normalized_shape) == 1 and x.shape[-1] == c):
+    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c % 4 == 0 and c <= 8192
+            and len(ln.normalized_shape) == 1 and x.shape[-1] == c):          # (the kernel keeps a row in registers: c <= 8192)
         x = x.contiguous()
         m = x.numel() // c
         if tokens_per_image:
@@ -817,6 +823,7 @@ def _conv_patch_tokens(conv, x, ln2d=None, nchw_out=False):
     if pl is None:
         pl = _ConvAsLinear(conv)
         conv.__dict__["_mirx_as_linear"] = pl
+    pl.__dict__["_mirx_cfg"] = _cfg(conv)          # the view runs under its conv's configuration
     pl.refresh()
     p = conv.kernel_size[0]
     b, c, h, w = x.shape
@@ -1437,6 +1444,7 @@ class _ConvNeXtV2Backbone(nn.Module):
                 if pl is None:
                     pl = _ConvAsLinear(conv, channels_last=True)
                     conv.__dict__["_mirx_as_linear_cl"] = pl
+                pl.__dict__["_mirx_cfg"] = _cfg(conv)
                 pl.refresh()
                 c = t.shape[-1]
                 rows = torch.empty((b * (h // 2) * (w // 2), 4 * c), dtype=torch.float32, device=dev)

@@ -128,6 +128,7 @@ class _EncoderLayer(nn.Module):
         lib = _lib.load()
         b1, b2 = _m._layernorm_bound(self.layer_norm1), _m._layernorm_bound(self.layer_norm2)
         pk = sa._packed.refresh()
+        pk.__dict__["_mirx_cfg"] = _m._cfg(sa)                   # the packed view runs under its attention module's configuration
         bctx, bh = _m._linear_out_bound(self.layer_norm1, sa.v_proj), _m._linear_out_bound(self.layer_norm2, mlp.fc1)
         # big batches: every Linear on the DMA-fed kernel, its input handed over as terms rows by the producer
         terms = _m._linear_terms_ok(self, b * n, (pk, sa.out_proj, mlp.fc1, mlp.fc2), (b1, b2, bctx, bh))

@@ -147,3 +147,22 @@ def test_tanh_gelu_sigmoid_form_is_as_accurate_as_the_tanh_form():
     big = np.abs(ref) > 1e-3
     rel = lambda x: float((np.abs(x - ref)[big] / np.abs(ref[big])).max())
     assert rel(got) < 2e-6 and rel(got) <= rel(tanh_form)
+
+
+def test_kernel_config_reaches_the_linear_views_that_are_not_modules():
+    """a patch-embedding / downsample conv seen as a Linear (_ConvAsLinear) and SigLIP's packed q / k / v rows
+    (_PackedRows) are plain objects, not nn.Modules -- configure() must reach them too, or A/B arms measured through it are mixed."""
+    import mirx.model as mm
+    from mirx.siglip import SiglipVisionTower
+    torch.manual_seed(0)
+    v = SiglipVisionTower(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, image_size=28, patch_size=14)
+    off = dataclasses.replace(mm.DEFAULT_CONFIG, linear_two_fp16=False)
+    mm.set_kernel_config(v, off)
+    packed = [m.__dict__["_packed"] for m in v.modules() if "_packed" in m.__dict__]
+    assert packed and all(mm._cfg(p) is off for p in packed)
+    conv = torch.nn.Conv2d(3, 8, 4, 4)
+    mm.set_kernel_config(conv, off)
+    view = mm._ConvAsLinear(conv)
+    conv.__dict__["_mirx_as_linear"] = view
+    mm.set_kernel_config(conv, off)
+    assert mm._cfg(view) is off
