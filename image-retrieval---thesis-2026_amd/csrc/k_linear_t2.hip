@@ -512,8 +512,13 @@ __global__ __launch_bounds__(256) void k_rows_to_terms(const float *__restrict__
 }  // namespace
 
 #if MIRX_LT2_EXP & 32
+// reads the stamps back AND clears them: a shape with fewer workgroups than the one measured before it would otherwise
+// carry that one's stamps in its upper entries (round 3's r03_linear_bench.txt: contaminated means)
 extern "C" int mirx_debug_lt2_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt2_stamps), sizeof(g_lt2_stamps));
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lt2_stamps), sizeof(g_lt2_stamps));
+    if (e != hipSuccess) return (int)e;
+    static unsigned long long zeros[4096 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lt2_stamps), zeros, sizeof(zeros));
 }
 #endif
 

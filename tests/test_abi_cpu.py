@@ -99,3 +99,15 @@ def test_diagnostic_switches_cannot_reach_the_shipped_library():
         assert bad.returncode != 0 and "without -DMIRX_DIAG" in bad.stderr
         ok = subprocess.run(base + ["-DMIRX_DIAG", "-DMIRX_C1H2_EXP_SKIP=2", os.path.join(csrc, "k_conv1x1_h2.hip")], capture_output=True, text=True)
         assert ok.returncode == 0, ok.stderr[-500:]
+
+
+def test_set_tuning_validates_its_arguments_without_a_gpu():
+    """mirx_set_tuning only stores a process-wide limit: callable on a box without a GPU; unknown keys and negative values fail
+    with MIRX_EINVAL and a message."""
+    from mirx import _lib as L
+    lib = L.load()
+    assert lib.mirx_set_tuning(L.TUNE_CONV1X1_SMALL_MAX_WG, 128) == 0
+    assert lib.mirx_set_tuning(L.TUNE_CONV3X3_SMALL_MAX_WG, 96) == 0
+    assert lib.mirx_set_tuning(99, 1) != 0 and b"unknown key" in lib.mirx_last_error()
+    assert lib.mirx_set_tuning(L.TUNE_CONV1X1_SMALL_MAX_WG, -1) != 0
+    assert lib.mirx_set_tuning(L.TUNE_CONV1X1_SMALL_MAX_WG, 128) == 0

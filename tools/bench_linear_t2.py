@@ -33,7 +33,8 @@ def timed(fn, iters):
 
 
 def stamps(name):
-    """Per-workgroup cycle stamps of the LAST launch (steady state of the timing loop), wave 0 of every workgroup."""
+    """Per-workgroup cycle stamps of the LAST launch (steady state of the timing loop), wave 0 of every workgroup.  The library
+    clears the buffer on every read-back, so a shape only ever shows its own workgroups."""
     import ctypes
     import numpy as np
     from mirx import _lib

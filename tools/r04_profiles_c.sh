@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-3 evidence for the token-major Linear kernels (run on the GPU box): micro benchmark of mirx_linear_terms against
+# Round-4 evidence for the token-major Linear kernels (run on the GPU box): micro benchmark of mirx_linear_terms against
 # mirx_linear_split2h on the DINOv2 / MedSigLIP layer shapes, the in-kernel cycle stamps of k_linear_t2 (diagnostic library
-# exp/liblt2_exp32.so, csrc/k_linear_t2.hip MIRX_LT2_EXP=32), and the PMC split of both kernels.  Outputs: gpurun_out/r03_linear_*.
+# exp/liblt2_exp32.so, csrc/k_linear_t2.hip MIRX_LT2_EXP=32), and the PMC split of both kernels.  Outputs: gpurun_out/r04_linear_*.
 cd $GRAFT_REPO_ROOT
 {
   for m in dinov2 medsiglip; do
@@ -12,6 +12,6 @@ cd $GRAFT_REPO_ROOT
     echo "== dinov2, cycle stamps of the last launch of each timing loop (wave 0 of every workgroup; diagnostic build)"
     MIRX_LIB_PATH=$GRAFT_REPO_ROOT/exp/liblt2_exp32.so timeout -k 10 200 python tools/bench_linear_t2.py --model dinov2 --no-check --iters 20 --stamps 2>&1 | grep stamps
   fi
-} > gpurun_out/r03_linear_bench.txt 2>&1
-bash tools/pmc_linear.sh dinov2 > gpurun_out/r03_linear_pmc.txt 2>&1
-tail -40 gpurun_out/r03_linear_bench.txt; cat gpurun_out/r03_linear_pmc.txt
+} > gpurun_out/r04_linear_bench.txt 2>&1
+bash tools/pmc_linear.sh dinov2 > gpurun_out/r04_linear_pmc.txt 2>&1
+tail -40 gpurun_out/r04_linear_bench.txt; cat gpurun_out/r04_linear_pmc.txt
