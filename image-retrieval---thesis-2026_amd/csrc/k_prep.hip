@@ -181,23 +181,25 @@ __global__ __launch_bounds__(256) void k_bn_relu(const float *__restrict__ x, in
 }
 
 // avgpool2x2(relu(bn(x))): one thread per pair of horizontally adjacent outputs = two 16-byte loads and
-// one 8-byte store; items are numbered (image, channel, output row, output column pair) in one flat grid
-// (odd output widths end each row with a single-output item).
+// one 8-byte store; items are numbered (channel, output row, output column pair) inside an image (blockIdx.y).
+// W > 0: the map is W x W with W known at compile time (DenseNet's 56 / 28 / 14: the index arithmetic is then a few
+// 32-bit multiplies; with run-time sizes its three 64-bit divisions cost more than the two loads), W = 0: any even h, w.
+template <int W>
 __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restrict__ x, int64_t xbs,
                                                           const float *__restrict__ scale,
-                                                          const float *__restrict__ shift, int c, int h,
-                                                          int w, int64_t items, float *__restrict__ y, int64_t xps) {
+                                                          const float *__restrict__ shift, int c, int h_,
+                                                          int w_, unsigned items, float *__restrict__ y, int64_t xps) {
+    const int h = W ? W : h_, w = W ? W : w_;
     const int oh = h >> 1, ow = w >> 1, pw = (ow + 1) >> 1;
-    const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned it = blockIdx.x * 256u + threadIdx.x;
     if (it >= items) return;
-    const int px = (int)(it % pw);
-    const int64_t t1 = it / pw;
-    const int oy = (int)(t1 % oh);
-    const int64_t t2 = t1 / oh;
-    const int ch = (int)(t2 % c);
-    const int64_t b = t2 / c;
+    const int64_t b = blockIdx.y;
+    const int px = (int)(it % (unsigned)pw);
+    const unsigned t1 = it / (unsigned)pw;
+    const int oy = (int)(t1 % (unsigned)oh);
+    const int ch = (int)(t1 / (unsigned)oh);
     const float sc = scale[ch], sh = shift[ch];
-    const float *xp = x + b * xbs + (int64_t)ch * xps + (int64_t)(2 * oy) * w + 4 * px;    // xps: channel-plane stride (>= h w)
+    const float *xp = x + b * xbs + (int64_t)ch * xps + (2 * oy) * w + 4 * px;    // xps: channel-plane stride (>= h w)
     float *yp = y + ((b * c + ch) * (int64_t)oh + oy) * ow + 2 * px;
     auto act = [&](float v) { return fmaxf(fmaf(v, sc, sh), 0.0f); };
     if (2 * px + 1 < ow) {
@@ -246,10 +248,17 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
     if (!x_plane_stride) x_plane_stride = (int64_t)h * w;
     if ((h & 1) || (w & 1) || (x_batch_stride & 1) || n > 65535 || c > 65535) return hipErrorInvalidValue;
     if (x_plane_stride < (int64_t)h * w || (x_plane_stride & 3)) return hipErrorInvalidValue;   // rows stay 16-byte aligned
-    const int64_t items = n * c * (int64_t)(h / 2) * ((w / 2 + 1) / 2);
-    if ((items + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_bn_relu_avgpool2, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, x, x_batch_stride,
-                       scale, shift, c, h, w, items, y, x_plane_stride);
+    const int64_t items = (int64_t)c * (h / 2) * ((w / 2 + 1) / 2);      // per image
+    if (items > 0x7fffff00LL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
+#define MIRX_POOL_LAUNCH(W_)                                                                                            \
+    hipLaunchKernelGGL(k_bn_relu_avgpool2<W_>, grid, dim3(256), 0, st, x, x_batch_stride, scale, shift, c, h, w,       \
+                       (unsigned)items, y, x_plane_stride)
+    if (h == w && w == 56) MIRX_POOL_LAUNCH(56);
+    else if (h == w && w == 28) MIRX_POOL_LAUNCH(28);
+    else if (h == w && w == 14) MIRX_POOL_LAUNCH(14);
+    else MIRX_POOL_LAUNCH(0);
+#undef MIRX_POOL_LAUNCH
     return hipGetLastError();
 }
 

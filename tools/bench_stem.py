@@ -23,8 +23,7 @@ def main():
     w2, osc = _stem_weights_split2h(torch.randn(64, 3, 7, 7, generator=g, device=dev) * 0.05)
     sc, sh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
     y = torch.empty(b, 64, 56, 56, device=dev)
-    rin, rout = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
-    rin[0] = float(x.abs().max())
+    rin, rout = x.abs().amax(dim=(1, 2, 3)).contiguous(), torch.zeros(b, device=dev)      # ranges are per image
     for it in range(12):
         if it == 2:
             torch.cuda.synchronize()
