@@ -114,6 +114,19 @@ __device__ inline void finish4(f32x4 v, int64_t row, int col, const f32x4 &bv, c
     }
 }
 
+// tile number -> (token tile, output tile).  The workgroups of an XCD run ~32 consecutive tile numbers at a time: bands of 8
+// token tiles are walked output tile by output tile, so that those 32 are 8 token tiles x 4 output tiles -- 12 operand tiles
+// come over the fabric per 32 products.  (Token-major numbering made them ~2 token tiles x every output tile: MedSigLIP's fc1,
+// 17 output tiles, fetched 19 per 32 -- 9 % more fabric traffic over its forward and 2 % slower; DINOv2, 3-12 output tiles:
+// equal.)  Any bijection is correct; the K-split tail takes the last numbers either way.
+__device__ __forceinline__ void lt2_tile_mn(int64_t tile, int ntn, int64_t mt, int64_t &tm, int &tn) {
+    const int64_t g = tile / (8 * (int64_t)ntn), base = g * 8;
+    const int gm = (int)(mt - base < 8 ? mt - base : 8);
+    const int i = (int)(tile - g * 8 * ntn);
+    tm = base + i % gm;
+    tn = i / gm;
+}
+
 // TAIL SPLIT.  One tile occupies one CU for its whole K loop, so a launch of T tiles on P CUs takes ceil(T / P) rounds: 516
 // tiles on 256 CUs (DINOv2's proj at 32 images) run as long as 768 would.  The launcher therefore runs only the first
 // floor(T / P) * P tiles whole ("plain"); each of the r remaining tiles is cut along K into `parts` = min(stages, P / r) pieces
@@ -137,8 +150,10 @@ __global__ __launch_bounds__(512, 2) void k_linear_t2(const char *__restrict__ x
         piece = (int)(blockIdx.x - 8 * per_xcd);
         tile = plain_tiles + piece / parts;
     }
-    const int tn = (int)(tile % ntn);
-    const int64_t m0 = (tile / ntn) * TM;
+    int tn;
+    int64_t tm_;
+    lt2_tile_mn(tile, ntn, (m + TM - 1) / TM, tm_, tn);
+    const int64_t m0 = tm_ * TM;
     const int n0 = tn * TN;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wtok = wave >> 2, wout = wave & 3;              // this wave: tokens 128 wtok .., outputs 64 wout ..
@@ -456,8 +471,11 @@ __global__ __launch_bounds__(256) void k_linear_t2_fix(const float *__restrict__
                                                        float y_scale, int np) {
     const int64_t st = blockIdx.x >> 6;
     const int64_t tile = plain_tiles + st;
-    const int n0 = (int)(tile % ntn) * TN;
-    const int64_t m0 = (tile / ntn) * TM;
+    int tn_;
+    int64_t tm_;
+    lt2_tile_mn(tile, ntn, (m + TM - 1) / TM, tm_, tn_);
+    const int n0 = tn_ * TN;
+    const int64_t m0 = tm_ * TM;
     const int col = n0 + 4 * (threadIdx.x & 63);
     const int rl = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6);
     const int64_t row = m0 + rl;

@@ -32,16 +32,14 @@ constexpr int PLANE = 3 * ITH * PH;          // floats per parity plane
 constexpr int OCB = 32;                      // output channels per MFMA row block
 constexpr int NOB = 2;                       // row blocks per workgroup: all 64 channels (a split B fragment feeds both)
 constexpr int NSTEP = 11;                    // MFMA steps: 22 (c, ky) rows, row 21 = zero weights
-constexpr int CONV_PITCH = 257;              // 255 pixels + pad; = 1 (mod 32): see the pooling phase
+constexpr int CONV_PITCH = 260;              // 255 pixels + pad, 260 = 4 (mod 32) banks per channel
 constexpr int S_IN = 2 * PLANE;
 constexpr int S_CONV = NOB * OCB * CONV_PITCH;
 constexpr int S_ALL = S_IN > S_CONV ? S_IN : S_CONV;
 constexpr int W_BYTES = NOB * NSTEP * 2 * OCB * 16 * 2;      // all weights of the stem: 44 pieces of 1 KiB
 constexpr int W_OFF = S_IN * 4;                              // behind the patch (the conv tile reuses both after the K loop)
 constexpr int PAR_OFF = (W_OFF + W_BYTES > S_ALL * 4 ? W_OFF + W_BYTES : S_ALL * 4);   // epilogue constants behind everything
-constexpr int POOL_OFF = PAR_OFF + 4 * NOB * OCB * 4;       // pooled half tile (32 channels x 8 x 7) on its way to coalesced stores
-constexpr int LDS_BYTES = POOL_OFF + 32 * PTH * PTW * 4;
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+constexpr int LDS_BYTES = PAR_OFF + 4 * NOB * OCB * 4;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 __device__ inline void split2(float a, float b, unsigned &h, unsigned &l) {
@@ -256,41 +254,21 @@ __global__ __launch_bounds__(256, 2) void k_stem_h2(const TIN *__restrict__ x, c
     __syncthreads();
 
     // ---- max-pool 3x3 / 2: only the pooled map goes to HBM ----------------------------------------
-    // A thread pools one (channel, pooled row): the three conv rows under it (45 words) -> 7 outputs.  Lane -> (r = lane & 7,
-    // kk = lane >> 3), channel = 2 (wave + 4 pass) + (kk & 1) + 16 (kk >> 1): with the tile pitch = 1 (mod 32) and the 30
-    // words between the rows of neighbouring r, the 64 lanes of a read fall on all 32 banks twice -- the floor.  (The first
-    // version gave a lane one output of one channel, nine reads at stride 2 along the row and 30 across rows: 15 banks for
-    // 56 lanes, and the pooling took as long as the MFMAs.)  The 7 outputs go through a small LDS stage so that the stores to
-    // HBM stay whole 28-byte row segments, a channel per wave instruction, as before.
     float *yi = y + img * y_bs + oc0 * (int64_t)ph * pw;   // y_bs: batch stride (the dense block's buffer)
-    float *s_pool = sm + POOL_OFF / 4;                     // [32 local channels][PTH][PTW]
     float vmax = 0.f;
-    const int p_r = lane & 7, p_kk = lane >> 3;
-#pragma unroll 1
-    for (int pass = 0; pass < ((MIRX_STEM_EXP & 4) ? 0 : 2); ++pass) {
-        const int oc = 2 * (wave + 4 * pass) + (p_kk & 1) + 16 * (p_kk >> 1);
-        const float *cb = s_conv + oc * CONV_PITCH + 2 * p_r * CTW;
-        float cm[CTW];
+    for (int i = threadIdx.x; i < ((MIRX_STEM_EXP & 4) ? 0 : NOB * OCB * PTH * 8); i += 256) {
+        const int oc = i / (PTH * 8), r = (i / 8) % PTH, q = i % 8;
+        const int py = py0 + r, px = px0 + q;
+        if (q < PTW && py < ph && px < pw) {
+            const float *cbase = s_conv + oc * CONV_PITCH + (2 * r) * CTW + 2 * q;
+            float m = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CTW; ++c) cm[c] = fmaxf(fmaxf(cb[c], cb[CTW + c]), cb[2 * CTW + c]);
-        float m[PTW];
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int q = 0; q < PTW; ++q) m[q] = fmaxf(fmaxf(cm[2 * q], cm[2 * q + 1]), cm[2 * q + 2]);
-        if (pass) __syncthreads();                         // the stores of pass 0 have read the stage
-#pragma unroll
-        for (int q = 0; q < PTW; ++q) s_pool[((wave * 8 + p_kk) * PTH + p_r) * PTW + q] = m[q];
-        __syncthreads();
-        // local channel l = 8 w + kk of this pass -> channel 2 (w + 4 pass) + (kk & 1) + 16 (kk >> 1)
-        for (int i = threadIdx.x; i < 32 * PTH * PTW; i += 256) {
-            const int l = i / (PTH * PTW), rem = i % (PTH * PTW), r = rem / PTW, q = rem % PTW;
-            const int oc_s = 2 * ((l >> 3) + 4 * pass) + (l & 1) + 16 * ((l & 7) >> 1);
-            const int py = py0 + r, px = px0 + q;
-            if (py < ph && px < pw) {
-                float mv = s_pool[i];
-                if (x_inv != x_inv) mv = x_inv;            // a non-finite input range: NaN out (relu and max above drop NaNs)
-                yi[((int64_t)oc_s * ph + py) * pw + px] = mv;
-                vmax = range_max(vmax, mv);
-            }
+                for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, cbase[dy * CTW + dx]);
+            if (x_inv != x_inv) m = x_inv;               // a non-finite input range: NaN out (relu and max above drop NaNs)
+            yi[((int64_t)oc * ph + py) * pw + px] = m;
+            vmax = range_max(vmax, m);
         }
     }
     if (out_range) range_publish(out_range, (int)img, vmax, threadIdx.x & 63);
