@@ -1180,7 +1180,7 @@ class DenseNet121(_Configurable, nn.Module):
         else:
             x = self.forward_eager(self.normalize_uint8(x) if x.dtype == torch.uint8 else x)
         if self.fc:
-            x = self.fc(x)
+            x = _linear_auto(self.fc, x)         # [HIP] three-bf16-term Linear on the inference path: no library GEMM in a forward
         if self.classification_head is not None:
             return {"embedding": F.normalize(x, dim=1), "logits": self.classification_head(x)}
         return F.normalize(x, dim=1)
@@ -1498,7 +1498,7 @@ class ConvNeXtV2(_Configurable, nn.Module):
         x = self.convnext(x)
         x = torch.flatten(x, 1)
         if self.fc:
-            x = self.fc(x)
+            x = _linear_auto(self.fc, x)         # [HIP] three-bf16-term Linear on the inference path: no library GEMM in a forward
         if x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.float32 and x.is_contiguous():
             from .index import l2_normalize_
             return l2_normalize_(x)                # HIP F.normalize (model.py:116)
@@ -1722,7 +1722,7 @@ class DinoV2(_Configurable, nn.Module):
     def forward(self, x):
         x = torch.flatten(self.backbone(x), 1)
         if self.fc:
-            x = self.fc(x)
+            x = _linear_auto(self.fc, x)         # [HIP] three-bf16-term Linear on the inference path: no library GEMM in a forward
         return _normalize_rows(x)
 
 
