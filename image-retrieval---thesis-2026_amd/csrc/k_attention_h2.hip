@@ -18,6 +18,15 @@ namespace {
 // wrapper was 4 of every 6 VALU instructions of the softmax.
 __device__ inline float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max of a value over the two 32-lane halves of the wave, in every lane: v_permlane32_swap (gfx950) hands each half the other's
+// value inside the vector unit -- the ds_bpermute of __shfl_xor(.., 32) was an LDS round trip on the critical path of every tile
+__device__ inline float max_over_halves(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+    const unsigned b = __float_as_uint(v);
+    const u32x2_ r = __builtin_amdgcn_permlane32_swap(b, b, false, false);    // r[0] = the low half's value, r[1] = the high half's
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;   // (fp16 here)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -130,18 +139,22 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
         const int d = 4 * vc + j;
         v_lds[j] = 2 * K_PLANE + d * 64 + ((((vpos >> 3) ^ ((d >> 2) & 3))) << 4) + (vpos & 7) * 2;   // + term * V_PLANE
     }
+    // K / V rows come through a buffer descriptor over THIS image's n token rows: a lane's byte offset inside a tile is fixed
+    // for the whole launch and the tile's offset is one scalar, so the loop holds no address arithmetic (it was ~40 of its ~250
+    // vector instructions: clamps, 32-bit multiplies, 64-bit adds); rows beyond n are out of range and read as zero -- their
+    // scores are set to -inf in the tail tile and their probabilities are exactly 0.
+    const __amdgpu_buffer_rsrc_t kvrs = __builtin_amdgcn_make_buffer_rsrc((void *)(qkv + img * n * tok), 0,
+                                                                          (unsigned)((int64_t)n * tok * 4), 0x00020000);
+    const unsigned vo_k = (unsigned)((kk * tok + (heads + head) * DH + 8 * kc) * 4);
+    const unsigned vo_v = (unsigned)((vkey * tok + (2 * heads + head) * DH + 4 * vc) * 4);
+    const unsigned row_b = (unsigned)(tok * 4), tile_b = (unsigned)(KT * tok * 4);
     f32x4 rk[2], rv[2];
     auto load_tile = [&](int kt) {
-        int key = kt * KT + kk;
-        if (key >= n) key = n - 1;                                        // masked later
-        const float *kp = base + key * tok + heads * DH + 8 * kc;
-        rk[0] = *reinterpret_cast<const f32x4 *>(kp);
-        rk[1] = *reinterpret_cast<const f32x4 *>(kp + 4);
-        int k0 = kt * KT + vkey, k1 = k0 + 1;
-        if (k0 >= n) k0 = n - 1;
-        if (k1 >= n) k1 = n - 1;                                          // P is 0 there
-        rv[0] = *reinterpret_cast<const f32x4 *>(base + k0 * tok + 2 * heads * DH + 4 * vc);
-        rv[1] = *reinterpret_cast<const f32x4 *>(base + k1 * tok + 2 * heads * DH + 4 * vc);
+        const unsigned so = (unsigned)kt * tile_b;                        // wave-uniform
+        rk[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_k, so, 0));
+        rk[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_k + 16u, so, 0));
+        rv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_v, so, 0));
+        rv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_v + row_b, so, 0));
     };
     auto store_tile = [&](int buf) {
         char *sb = sm + buf * BUF;
@@ -208,13 +221,19 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
         const int key0 = kt * KT + 4 * half;
         const bool tail_tile = (kt + 1) * KT > n;          // wave-uniform: only the last tile can hold keys beyond n
         float mt = -INFINITY;
+        if (tail_tile) {
+            // a real branch (the empty asm keeps the compiler from turning it into 16 compares, 16 selects and 16 scalar ORs
+            // executed for EVERY tile: a fifth of the loop's vector instructions)
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 8 * (r >> 2) + (r & 3);
-            if (tail_tile && key >= n) sacc[r] = -INFINITY;
-            mt = fmaxf(mt, sacc[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 8 * (r >> 2) + (r & 3);
+                if (key >= n) sacc[r] = -INFINITY;
+            }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * s_inv;    // the other 16 keys of the same query; max commutes with the positive scale
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
+        mt = max_over_halves(mt) * s_inv;    // the other 16 keys of the same query; max commutes with the positive scale
         const float m_new = fmaxf(m_run, mt);              // finite: every tile holds at least one valid key
         const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
@@ -322,27 +341,35 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
         m = it / (DH / 4);
         vc = it % (DH / 4);
     };
+    // (buffer loads with one scalar tile offset: see k_attention_h2)
+    const __amdgpu_buffer_rsrc_t kvrs = __builtin_amdgcn_make_buffer_rsrc((void *)(qkv + img * n * tok), 0,
+                                                                          (unsigned)((int64_t)n * tok * 4), 0x00020000);
+    const unsigned row_b = (unsigned)(tok * 4), tile_b = (unsigned)(KT * tok * 4);
+    unsigned vo_k[IPK], vo_v[IPV];
+#pragma unroll
+    for (int i = 0; i < IPK; ++i) {
+        int key, c; bool live;
+        k_item(i, key, c, live);
+        const int cc = 8 * c < DH ? 8 * c : DH - 8;                        // pad chunk: read something valid, store zeros
+        vo_k[i] = (unsigned)((key * tok + (heads + head) * DH + cc) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IPV; ++i) {
+        int m, vc; bool live;
+        v_item(i, m, vc, live);
+        vo_v[i] = (unsigned)((2 * m * tok + (2 * heads + head) * DH + 4 * vc) * 4);
+    }
     auto load_tile = [&](int kt) {
+        const unsigned so = (unsigned)kt * tile_b;                        // wave-uniform
 #pragma unroll
         for (int i = 0; i < IPK; ++i) {
-            int key, c; bool live;
-            k_item(i, key, c, live);
-            int g = kt * KT + key;
-            if (g >= n) g = n - 1;
-            const int cc = 8 * c < DH ? 8 * c : DH - 8;                    // pad chunk: read something valid, store zeros
-            const float *kp = base + g * tok + heads * DH + cc;
-            rk[i][0] = *reinterpret_cast<const f32x4 *>(kp);
-            rk[i][1] = *reinterpret_cast<const f32x4 *>(kp + 4);
+            rk[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_k[i], so, 0));
+            rk[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_k[i] + 16u, so, 0));
         }
 #pragma unroll
         for (int i = 0; i < IPV; ++i) {
-            int m, vc; bool live;
-            v_item(i, m, vc, live);
-            int k0 = kt * KT + 2 * m, k1 = k0 + 1;
-            if (k0 >= n) k0 = n - 1;
-            if (k1 >= n) k1 = n - 1;
-            rv[i][0] = *reinterpret_cast<const f32x4 *>(base + k0 * tok + 2 * heads * DH + 4 * vc);
-            rv[i][1] = *reinterpret_cast<const f32x4 *>(base + k1 * tok + 2 * heads * DH + 4 * vc);
+            rv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_v[i], so, 0));
+            rv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kvrs, vo_v[i] + row_b, so, 0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -431,13 +458,19 @@ __global__ __launch_bounds__(256, 2) void k_attention_h2g(const float *__restric
         const int key0 = kt * KT + 4 * half;
         const bool tail_tile = (kt + 1) * KT > n;          // wave-uniform: only the last tile can hold keys beyond n
         float mt = -INFINITY;
+        if (tail_tile) {
+            // a real branch (the empty asm keeps the compiler from turning it into 16 compares, 16 selects and 16 scalar ORs
+            // executed for EVERY tile: a fifth of the loop's vector instructions)
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + 8 * (r >> 2) + (r & 3);
-            if (tail_tile && key >= n) sacc[r] = -INFINITY;
-            mt = fmaxf(mt, sacc[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 8 * (r >> 2) + (r & 3);
+                if (key >= n) sacc[r] = -INFINITY;
+            }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * s_inv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[r]);
+        mt = max_over_halves(mt) * s_inv;
         const float m_new = fmaxf(m_run, mt);
         const float alpha = exp2_raw(m_run - m_new);
         float psum = 0.0f;
@@ -512,6 +545,7 @@ hipError_t launch_attention_h2(const float *qkv, int64_t batch, int n, int heads
     if (head_dim != DH && head_dim != 72 && head_dim != 96 && head_dim != 32) return hipErrorInvalidValue;
     if (!(qk_bound > 0.f) || !(v_bound > 0.f) || !(scale > 0.f)) return hipErrorInvalidValue;
     if ((out != nullptr) == (out_terms != nullptr) || (heads * head_dim) % 4) return hipErrorInvalidValue;
+    if ((int64_t)n * 3 * heads * head_dim * 4 >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // an image's qkv rows: 32-bit buffer offsets
     const float sl = scale * 1.4426950408889634f;
     // powers of two that bring each operand's bound to at most 2^14 (fp16 max 65504)
     const float qs = exp2f(floorf(log2f(16384.0f / (qk_bound * sl))));
