@@ -92,6 +92,8 @@ SYMBOLS = {
     "mirx_dense_layer_fused": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "mirx_conv3x3_direct_terms_nchw": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "mirx_conv3x3_direct_terms_nchw_pool": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "mirx_conv3x3_small_launch": (_int, [_i64, _int]),
     "mirx_conv3x3_winograd_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_direct_split3_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
     "mirx_conv3x3_winograd_nchw": (_int, [_vp, _vp, _i64, _int, _vp, _i64, _vp]),
@@ -104,6 +106,7 @@ SYMBOLS = {
     "mirx_bn_relu_gap_l2norm": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_bn_relu_nchw": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp]),
     "mirx_bn_relu_avgpool2": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _vp]),
+    "mirx_bn_relu_avgpool2_into": (_int, [_vp, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _i64, _i64, _vp]),
     "mirx_conv1x1_bn_relu": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_dwconv7x7_nchw_to_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "mirx_dwconv7x7_nhwc": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
@@ -112,7 +115,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 304          # include/mirx.h MIRX_VERSION this binding was written against
+ABI_VERSION = 305          # include/mirx.h MIRX_VERSION this binding was written against
 
 
 def load():

@@ -56,7 +56,9 @@ template <int W, int R, int IPW = 1, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const uint16_t *__restrict__ yt, const uint16_t *__restrict__ w3,
                                                         const float *__restrict__ oscale, float *__restrict__ out,
                                                         int64_t out_bs, const float *__restrict__ in_inv,
-                                                        unsigned *__restrict__ out_range, int64_t out_ps, int64_t n_img) {
+                                                        unsigned *__restrict__ out_range, int64_t out_ps, int64_t n_img,
+                                                        const float *__restrict__ pool_sc, const float *__restrict__ pool_sh,
+                                                        float *__restrict__ pool_out, int64_t pool_bs) {
     constexpr int PW = W + 2, PR = R + 2;     // padded strip
     static_assert(IPW == 1 || R == W, "several images per workgroup: whole images only");
     constexpr int NPIX = IPW * PR * PW;       // padded pixels of a stage
@@ -226,6 +228,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const 
     float osc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) osc[r] = oscale[8 * (r >> 2) + (r & 3) + 4 * half];
+    // POOLED TWIN (pool_out != nullptr; dense blocks 1-3, whose transition starts with norm + relu + avgpool 2x2): the strip
+    // holds whole row pairs, so this workgroup also writes avgpool2(relu(bn_t(v))) of its 32 new channels into the transition's
+    // pooled input -- the same fp32 operations in the same order as mirx_bn_relu_avgpool2 on the stored values, bit-identical
+    // -- and the pooling pass over the whole block (every channel read once more from HBM) shrinks to the block's first
+    // channels.  The activated values cross lanes through the LDS the K loop has released.
+    constexpr int ACT_PITCH = NOUT + 1;                       // odd: the lanes of a pooled read fall on different banks
+    float *s_act = reinterpret_cast<float *>(sm);             // [32 channels][ACT_PITCH]
+    const bool pooled_twin = IPW == 1 && pool_out != nullptr; // wave-uniform
+    float psc[16], psh[16];
+    if (pooled_twin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            psc[r] = pool_sc[8 * (r >> 2) + (r & 3) + 4 * half];
+            psh[r] = pool_sh[8 * (r >> 2) + (r & 3) + 4 * half];
+        }
+        __syncthreads();                                      // every wave has read its last fragments: the stage buffers are free
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int p = (wave + NW * t) * 32 + n;
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const 
                 const float v = acc[t][r] * (osc[r] * x_inv);
                 vmax = range_max(vmax, v);
                 op[(int64_t)oc * out_ps] = v;
+                if (pooled_twin) s_act[oc * ACT_PITCH + p] = fmaxf(fmaf(v, psc[r], psh[r]), 0.0f);
             }
         }
         if (out_range && live_blk[t]) {                                // wave-uniform
@@ -249,11 +269,28 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void k_conv3x3_d2p(const 
             else range_publish_lanes(out_range, pimg, vmax, lane);
         }
     }
+    if constexpr (IPW == 1) {
+        if (pooled_twin) {
+            __syncthreads();
+            constexpr int W2 = W / 2, R2 = R / 2, NP2 = R2 * W2;      // pooled pixels of the strip, per channel
+            static_assert(R % 2 == 0 && W % 2 == 0, "whole row pairs");
+            const int rows_here = W - oy0 < R ? W - oy0 : R;          // the map's last strip may be short (an even number of rows)
+            float *po = pool_out + img * pool_bs + (int64_t)(oy0 / 2) * W2;
+            for (int i = threadIdx.x; i < COUT * NP2; i += 64 * NW) {
+                const int oc = i / NP2, q = i % NP2, py = q / W2, px = q % W2;
+                if (2 * py < rows_here) {
+                    const float *a = s_act + oc * ACT_PITCH + (2 * py) * W + 2 * px;
+                    po[(int64_t)oc * (W2 * W2) + q] = (a[0] + a[1] + a[W] + a[W + 1]) * 0.25f;
+                }
+            }
+        }
+    }
 }
 
 template <int W, int R, int IPW = 1, int NW = 4>
 hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, float *out, int64_t out_bs,
-                      const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
+                      const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st, const float *pool_sc = nullptr,
+                      const float *pool_sh = nullptr, float *pool_out = nullptr, int64_t pool_bs = 0) {
     constexpr int NP = (IPW * (R + 2) * (W + 2) + 31) / 32;
     const size_t lds = (size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2;
     static_assert((size_t)2 * 2 * NP * 1024 + 2 * 9 * 2 * 32 * 16 * 2 <= 160 * 1024, "LDS of one CU");
@@ -264,36 +301,47 @@ hipError_t launch_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscal
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_conv3x3_d2p<W, R, IPW, NW>), dim3((W + R - 1) / R, (unsigned)((n + IPW - 1) / IPW)), dim3(64 * NW), lds,
-                       st, yt, w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n);
+                       st, yt, w2, oscale, out, out_bs, in_inv, reinterpret_cast<unsigned *>(out_range), out_ps, n, pool_sc, pool_sh,
+                       pool_out, pool_bs);
     return hipGetLastError();
 }
 
 }  // namespace
 
+// does a launch of n images take the one-wave-per-block kernel (k_conv3x3_d2s.hip)?  (the pooled twin exists in the strip
+// kernel only: the caller asks before it plans a block)
+bool conv3x3_takes_small(int64_t n, int side) {
+    const int64_t wgs = side == 56 ? 14 * n : side == 28 ? 4 * n : side == 14 ? n : (n + 3) / 4;
+    return wgs < conv3x3_small_max_wg();
+}
+
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st) {
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st,
+                              const float *pool_sc, const float *pool_sh, float *pool_out, int64_t pool_bs) {
     if (n <= 0) return hipSuccess;
     if (n > 65535 || !in_inv || !oscale) return hipErrorInvalidValue;
     if (!out_ps) out_ps = (int64_t)side * side;
     if (out_ps < (int64_t)side * side) return hipErrorInvalidValue;
+    if (pool_out && (!pool_sc || !pool_sh || side == 7 || pool_bs < (int64_t)COUT * (side / 2) * (side / 2)))
+        return hipErrorInvalidValue;
     // small launches (the reference's own batch sizes): one wave per block of 32 output pixels, no LDS (k_conv3x3_d2s.hip)
-    {
-        const int64_t wgs = side == 56 ? 14 * n : side == 28 ? 4 * n : side == 14 ? n : (n + 3) / 4;
-        if (wgs < conv3x3_small_max_wg())
-            return launch_conv3x3_d2s(yt, w2, oscale, n, side, out, out_bs, in_inv, out_range, out_ps, st);
+    if (conv3x3_takes_small(n, side)) {
+        if (pool_out) return hipErrorInvalidValue;            // the pooled twin lives in the strip kernel (conv3x3_takes_small)
+        return launch_conv3x3_d2s(yt, w2, oscale, n, side, out, out_bs, in_inv, out_range, out_ps, st);
     }
 #ifndef MIRX_D2P_WAVES
 #define MIRX_D2P_WAVES 4          // 8: one 8-wave workgroup per CU on twice the pixels (the A/B arm, measured slower)
 #endif
 #if MIRX_D2P_WAVES == 8
+    if (pool_out) return hipErrorInvalidValue;
     if (side == 56) return launch_d2p<56, 8, 1, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 28) return launch_d2p<28, 14, 1, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 14) return launch_d2p<14, 14, 2, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
     if (side == 7) return launch_d2p<7, 7, 8, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
 #else
-    if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
-    if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
-    if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
+    if (side == 56) return launch_d2p<56, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st, pool_sc, pool_sh, pool_out, pool_bs);
+    if (side == 28) return launch_d2p<28, 8>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st, pool_sc, pool_sh, pool_out, pool_bs);
+    if (side == 14) return launch_d2p<14, 14>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st, pool_sc, pool_sh, pool_out, pool_bs);
     if (side == 7) return launch_d2p<7, 7, 4>(yt, w2, oscale, n, out, out_bs, in_inv, out_range, out_ps, st);
 #endif
     return hipErrorInvalidValue;

@@ -188,7 +188,8 @@ template <int W>
 __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restrict__ x, int64_t xbs,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int c, int h_,
-                                                          int w_, unsigned items, float *__restrict__ y, int64_t xps) {
+                                                          int w_, unsigned items, float *__restrict__ y, int64_t xps,
+                                                          int64_t ybs) {
     const int h = W ? W : h_, w = W ? W : w_;
     const int oh = h >> 1, ow = w >> 1, pw = (ow + 1) >> 1;
     const unsigned it = blockIdx.x * 256u + threadIdx.x;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_avgpool2(const float *__restric
     const int ch = (int)(t1 / (unsigned)oh);
     const float sc = scale[ch], sh = shift[ch];
     const float *xp = x + b * xbs + (int64_t)ch * xps + (2 * oy) * w + 4 * px;    // xps: channel-plane stride (>= h w)
-    float *yp = y + ((b * c + ch) * (int64_t)oh + oy) * ow + 2 * px;
+    float *yp = y + b * ybs + ((int64_t)ch * oh + oy) * ow + 2 * px;            // ybs: batch stride of y (>= c oh ow)
     auto act = [&](float v) { return fmaxf(fmaf(v, sc, sh), 0.0f); };
     if (2 * px + 1 < ow) {
         float4 r0, r1;
@@ -243,9 +244,11 @@ hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const flo
 
 hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
                                    const float *shift, int64_t n, int c, int h, int w, float *y,
-                                   int64_t x_plane_stride, hipStream_t st) {
+                                   int64_t x_plane_stride, hipStream_t st, int64_t y_batch_stride) {
     if (n <= 0) return hipSuccess;
     if (!x_plane_stride) x_plane_stride = (int64_t)h * w;
+    if (!y_batch_stride) y_batch_stride = (int64_t)c * (h / 2) * (w / 2);
+    if (y_batch_stride < (int64_t)c * (h / 2) * (w / 2) || (y_batch_stride & 1)) return hipErrorInvalidValue;
     if ((h & 1) || (w & 1) || (x_batch_stride & 1) || n > 65535 || c > 65535) return hipErrorInvalidValue;
     if (x_plane_stride < (int64_t)h * w || (x_plane_stride & 3)) return hipErrorInvalidValue;   // rows stay 16-byte aligned
     const int64_t items = (int64_t)c * (h / 2) * ((w / 2 + 1) / 2);      // per image
@@ -253,7 +256,7 @@ hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const
     const dim3 grid((unsigned)((items + 255) / 256), (unsigned)n);
 #define MIRX_POOL_LAUNCH(W_)                                                                                            \
     hipLaunchKernelGGL(k_bn_relu_avgpool2<W_>, grid, dim3(256), 0, st, x, x_batch_stride, scale, shift, c, h, w,       \
-                       (unsigned)items, y, x_plane_stride)
+                       (unsigned)items, y, x_plane_stride, y_batch_stride)
     if (h == w && w == 56) MIRX_POOL_LAUNCH(56);
     else if (h == w && w == 28) MIRX_POOL_LAUNCH(28);
     else if (h == w && w == 14) MIRX_POOL_LAUNCH(14);

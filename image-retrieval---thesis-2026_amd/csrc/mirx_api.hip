@@ -790,6 +790,31 @@ int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const fl
     return MIRX_OK;
 }
 
+int mirx_conv3x3_direct_terms_nchw_pool(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                        int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                        int64_t out_plane_stride, const float *pool_scale, const float *pool_shift,
+                                        float *pooled, int64_t pooled_batch_stride, void *stream) {
+    MIRX_CHECK(n >= 0 && n <= 65535, "conv3x3_terms_pool: batch must be in [0, 65535]");
+    MIRX_CHECK(side == 56 || side == 28 || side == 14, "conv3x3_terms_pool: side must be 56, 28 or 14");
+    MIRX_CHECK(n == 0 || (y_terms && w2 && oscale && out && y_inv && pool_scale && pool_shift && pooled),
+               "conv3x3_terms_pool: null buffer");
+    if (!out_plane_stride) out_plane_stride = (int64_t)side * side;
+    MIRX_CHECK(out_plane_stride >= (int64_t)side * side, "conv3x3_terms_pool: the plane stride is 0 (= side^2) or at least side^2");
+    MIRX_CHECK(out_batch_stride >= 32 * out_plane_stride, "conv3x3_terms_pool: output batch stride too small");
+    MIRX_CHECK(pooled_batch_stride >= (int64_t)32 * (side / 2) * (side / 2), "conv3x3_terms_pool: pooled batch stride too small");
+    MIRX_CHECK(!conv3x3_takes_small(n, side),
+               "conv3x3_terms_pool: a launch this small runs on the one-wave-per-block kernel, which has no pooled twin "
+               "(mirx_conv3x3_small_launch tells; use mirx_conv3x3_direct_terms_nchw + mirx_bn_relu_avgpool2)");
+    MIRX_HIP(launch_conv3x3_d2p(reinterpret_cast<const uint16_t *>(y_terms), reinterpret_cast<const uint16_t *>(w2), oscale, n,
+                                side, out, out_batch_stride, y_inv, out_range_or_null, out_plane_stride,
+                                reinterpret_cast<hipStream_t>(stream), pool_scale, pool_shift, pooled, pooled_batch_stride));
+    return MIRX_OK;
+}
+
+int mirx_conv3x3_small_launch(int64_t n, int side) {
+    return (side == 56 || side == 28 || side == 14 || side == 7) && n > 0 && conv3x3_takes_small(n, side) ? 1 : 0;
+}
+
 int mirx_dense_layer_fused(float *buf, int64_t batch_stride, int64_t plane_stride, int cin, const float *scale1,
                            const float *shift1, const void *w2, const float *oscale, const float *bias, const void *c3w2,
                            const float *c3oscale, int64_t n, int side, float *range_row, float in_ks, float in_kb, float y_ks,
@@ -1150,6 +1175,21 @@ int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *s
                "bn_relu_avgpool2: the plane stride is 0 (= h * w) or a multiple of 4 that is at least h * w");
     MIRX_HIP(launch_bn_relu_avgpool2(x, x_batch_stride, scale, shift, n, c, h, w, y, x_plane_stride,
                                      reinterpret_cast<hipStream_t>(stream)));
+    return MIRX_OK;
+}
+
+int mirx_bn_relu_avgpool2_into(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
+                               int64_t n, int c, int h, int w, float *y, int64_t y_batch_stride, int64_t x_plane_stride,
+                               void *stream) {
+    MIRX_CHECK(x && scale && shift && y && n >= 0 && c >= 1, "bn_relu_avgpool2_into: bad argument");
+    MIRX_CHECK(h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && x_batch_stride % 2 == 0,
+               "bn_relu_avgpool2_into: h, w and the batch stride must be even");
+    MIRX_CHECK(x_plane_stride == 0 || (x_plane_stride >= (int64_t)h * w && x_plane_stride % 4 == 0),
+               "bn_relu_avgpool2_into: the plane stride is 0 (= h * w) or a multiple of 4 that is at least h * w");
+    MIRX_CHECK(y_batch_stride >= (int64_t)c * (h / 2) * (w / 2) && y_batch_stride % 2 == 0,
+               "bn_relu_avgpool2_into: the output batch stride must be even and at least c * (h / 2) * (w / 2)");
+    MIRX_HIP(launch_bn_relu_avgpool2(x, x_batch_stride, scale, shift, n, c, h, w, y, x_plane_stride,
+                                     reinterpret_cast<hipStream_t>(stream), y_batch_stride));
     return MIRX_OK;
 }
 

@@ -22,7 +22,7 @@ hipError_t launch_bn_relu_nchw(const float *x, int64_t x_batch_stride, const flo
                                const float *shift, int64_t n, int c, int hw, float *y, hipStream_t st);
 hipError_t launch_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
                                    const float *shift, int64_t n, int c, int h, int w, float *y,
-                                   int64_t x_plane_stride, hipStream_t st);
+                                   int64_t x_plane_stride, hipStream_t st, int64_t y_batch_stride = 0);
 hipError_t launch_stem(const float *x, const float *w, const float *scale, const float *shift,
                        int64_t n, int h, int wd, float *y, hipStream_t st);
 // k_stem_s3.hip: the same stem on three-term bf16 MFMAs; w3 = pre-split weights [2][11][3][32][16] bf16
@@ -146,8 +146,13 @@ hipError_t launch_attention_small(const float *q, int64_t q_rs, const float *k, 
                                   float scale, float *out, hipStream_t st);
 
 // k_conv3x3_d2h.hip, second kernel: the input already split into fp16 terms by launch_conv1x1_h2(.., y_inv_out != null)
+// pool_out != nullptr (sides 56 / 28 / 14, strip kernel only -- ask conv3x3_takes_small first): the launch also writes
+// avgpool2x2(relu(v * pool_sc[oc] + pool_sh[oc])) of its 32 output channels to pool_out[image * pool_bs + oc * (side/2)^2 + ..]
 hipError_t launch_conv3x3_d2p(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,
-                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st);
+                              int64_t out_bs, const float *in_inv, float *out_range, int64_t out_ps, hipStream_t st,
+                              const float *pool_sc = nullptr, const float *pool_sh = nullptr, float *pool_out = nullptr,
+                              int64_t pool_bs = 0);
+bool conv3x3_takes_small(int64_t n, int side);
 
 // k_conv3x3_d2s.hip: the same contract for small launches (one wave per 32 output pixels, no LDS); bit-identical results
 hipError_t launch_conv3x3_d2s(const uint16_t *yt, const uint16_t *w2, const float *oscale, int64_t n, int side, float *out,

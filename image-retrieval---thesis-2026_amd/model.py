@@ -93,6 +93,7 @@ class KernelConfig:
     densenet_two_fp16: bool = True          # DenseNet at 224 x 224: every conv on two fp16 terms, per-image value ranges
     plane_stride: tuple = ()                # ((side, floats between channel planes), ..): padded block buffers (measured: no gain)
     fused_small_maps: bool = False          # 14 x 14 / 7 x 7 dense layers in ONE launch (mirx_dense_layer_fused; slower so far)
+    pooled_twin: bool = True                # DenseNet: the transition's norm + relu + avgpool of a layer's new channels written by its 3x3 launch
     hip_stem: bool = True                   # legacy (not 224 x 224) path: the stem kernel (False: torch ops)
     stem_three_bf16: bool = True            #   .. on three bf16 terms (False: fp32 MFMAs)
     hip_conv1x1: bool = True                #   fused 1x1 convs (False: rocBLAS via torch)
@@ -289,14 +290,17 @@ def _plane_stride(side, cfg=DEFAULT_CONFIG):
     return ps
 
 
-def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None, fused_small=False):
+def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None, fused_small=False, pool=None):
     """One dense block on the two-fp16-term kernels.  `buf` [B, block.cout, plane stride] (side x side pixels per plane, see
     _plane_stride) already holds the first block.cin channels and `brange` (range row [B]: one float per image) bounds them.
     56 / 28 maps, every layer: conv1x1 (norm1 + relu1 prologue, norm2 + relu2 epilogue) writes the bottleneck ALREADY SPLIT
     into fp16 terms, image b scaled by a bound derived from brange[b] before the kernel runs (2^-t goes to the layer's row of
     `lranges`); conv3x3 stages those terms by DMA, writes 32 channels into the buffer and folds their range into brange.
     14 / 7 maps with `fused_small`: ONE launch per layer, mirx_dense_layer_fused -- the bottleneck of a 196-pixel unit stays in
-    the CU's LDS; bit-identical to the two launches and, so far, slower than them, hence opt-in."""
+    the CU's LDS; bit-identical to the two launches and, so far, slower than them, hence opt-in.
+    `pool` = (scale, shift, pooled) of the transition behind the block: every 3x3 launch then also writes norm + relu + avgpool2
+    of its 32 new channels into `pooled` [B, block.cout, side/2, side/2] (mirx_conv3x3_direct_terms_nchw_pool; the caller has
+    checked that the launches take the strip kernel)."""
     lib = _lib.load()
     b, _, ps = buf.shape
     h = w = side
@@ -322,28 +326,45 @@ def _dense_block_h2(block, buf, side, brange, cache, lranges, timer=None, fused_
                                                           _ptr(brange), e["ks"], e["kb"], e["yks"], e["ykb"],
                                                           _ptr(lranges[li]), ps, st), "mirx_conv1x1_bn_relu_split2h_terms")
         _timer_stop(timer, ev, 2.0 * b * h * w * c * y.shape[1], 4.0 * b * h * w * (c + y.shape[1]), "conv1x1")
-        _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
-                                                      block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
-                   "mirx_conv3x3_direct_terms_nchw")
+        if pool is not None and not fused:
+            psc, psh, pooled = pool
+            hw2 = (h // 2) * (w // 2)
+            _lib.check(lib.mirx_conv3x3_direct_terms_nchw_pool(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
+                                                               block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps,
+                                                               ctypes.c_void_p(psc.data_ptr() + 4 * c),
+                                                               ctypes.c_void_p(psh.data_ptr() + 4 * c),
+                                                               ctypes.c_void_p(pooled.data_ptr() + 4 * c * hw2),
+                                                               block.cout * hw2, st),
+                       "mirx_conv3x3_direct_terms_nchw_pool")
+        else:
+            _lib.check(lib.mirx_conv3x3_direct_terms_nchw(_ptr(y), _ptr(e["c3w2p"]), _ptr(e["c3osc"]), b, h, dst,
+                                                          block.cout * ps, _ptr(lranges[li]), _ptr(brange), ps, st),
+                       "mirx_conv3x3_direct_terms_nchw")
         c += GROWTH
     return buf
 
 
-def _transition_h2(buf, side, cache, brange, next_buf, next_range, timer=None):
+def _transition_h2(buf, side, cache, brange, next_buf, next_range, timer=None, pooled=None, pooled_from=0):
     """norm -> relu -> avgpool2 -> conv 1x1 (the pool commutes with the linear conv; two fp16 terms; the pooled values are
     averages of relu(bn(x)), so max|scale| * range + max|shift| bounds them) written into the channel prefix of the next
     block's buffer [B, C', its plane stride], whose range row receives the output ranges: a bn + relu + avgpool pass feeds
     the plain 1x1 conv.  (A one-launch form with the pool inside the conv's staging measured equal in round 2 -- every
-    128-channel output tile re-reads the un-pooled map -- and was dropped.)"""
+    128-channel output tile re-reads the un-pooled map -- and was dropped.)
+    `pooled` given: the block's 3x3 launches have already written the channels from `pooled_from` on (their pooled twin);
+    the pooling pass then covers only the block's first `pooled_from` channels."""
     lib = _lib.load()
     b, c, ps = buf.shape
     h = w = side
     st = _stream(buf.device)
     hw2 = (h // 2) * (w // 2)
     nps = next_buf.shape[2]
-    pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
-    _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * ps, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled), ps,
-                                         st), "mirx_bn_relu_avgpool2")
+    if pooled is None:
+        pooled = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=buf.device)
+        _lib.check(lib.mirx_bn_relu_avgpool2(_ptr(buf), c * ps, _ptr(cache["sc"]), _ptr(cache["sh"]), b, c, h, w, _ptr(pooled), ps,
+                                             st), "mirx_bn_relu_avgpool2")
+    else:
+        _lib.check(lib.mirx_bn_relu_avgpool2_into(_ptr(buf), c * ps, _ptr(cache["sc"]), _ptr(cache["sh"]), b, pooled_from, h, w,
+                                                  _ptr(pooled), c * hw2, ps, st), "mirx_bn_relu_avgpool2_into")
     ev = _timer_start(timer)
     _lib.check(lib.mirx_conv1x1_bn_relu_split2h(_ptr(pooled), c * hw2, c, None, None, _ptr(cache["w2"]), _ptr(cache["osc"]),
                                                 None, b, hw2, c // 2, 0, _ptr(next_buf), next_buf.shape[1] * nps,
@@ -1136,10 +1157,19 @@ class DenseNet121(_Configurable, nn.Module):
 
         def block_and_transition(k, bk, nxt):
             name, blk = blocks[k]
+            # the transition's norm + relu + avgpool of every NEW channel comes out of the 3x3 launch that writes it (its pooled
+            # twin: the strip kernel only, so not for launches small enough for the one-wave-per-block kernel)
+            pool = None
+            if (nxt is not None and cfg.pooled_twin and not (cfg.fused_small_maps and sides[k] in (14, 7))
+                    and not lib.mirx_conv3x3_small_launch(bk.shape[0], sides[k])):
+                t = h2[trans[k]]
+                pool = (t["sc"], t["sh"], torch.empty((bk.shape[0], blk.cout, sides[k] // 2, sides[k] // 2),
+                                                      dtype=torch.float32, device=dev))
             _dense_block_h2(blk, bk, sides[k], ranges[k], h2[name], ranges[rows[k]:rows[k] + len(blk)], self.conv1x1_timer,
-                            cfg.fused_small_maps)
+                            cfg.fused_small_maps, pool)
             if nxt is not None:
-                _transition_h2(bk, sides[k], h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer)
+                _transition_h2(bk, sides[k], h2[trans[k]], ranges[k], nxt, ranges[k + 1], self.conv1x1_timer,
+                               pool[2] if pool else None, blk.cin)
 
         def new_buf(k, n):
             return torch.empty((n, blocks[k][1].cout, _plane_stride(sides[k], cfg)), dtype=torch.float32, device=dev)

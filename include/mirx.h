@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIRX_VERSION 304
+#define MIRX_VERSION 305
 
 #define MIRX_OK 0
 #define MIRX_EINVAL (-1)   /* bad argument (null pointer, dim mismatch, k out of range) */
@@ -253,6 +253,22 @@ int mirx_conv1x1_bn_relu_split2h_terms(const float *x, int64_t x_batch_stride, i
 int mirx_conv3x3_direct_terms_nchw(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
                                    int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
                                    int64_t out_plane_stride, void *stream);
+/*
+ * mirx_conv3x3_direct_terms_nchw_pool (sides 56 / 28 / 14): the same launch ALSO writes the transition's pooled input for
+ * its 32 new channels -- pooled[b, oc] = avgpool2x2(relu(out[b, oc] * pool_scale[oc] + pool_shift[oc])) with images
+ * `pooled_batch_stride` floats apart and packed (side/2)^2 planes; pool_scale / pool_shift / pooled already point at this
+ * layer's first channel.  The values are computed from the stored fp32 outputs by the same operations in the same order as
+ * mirx_bn_relu_avgpool2: bit-identical to running that pass afterwards, without reading the block's map from HBM again
+ * (the transition's mirx_bn_relu_avgpool2_into then covers only the block's first channels).  Exists in the strip kernel
+ * only: mirx_conv3x3_small_launch(n, side) = 1 means a launch of n images takes the one-wave-per-block kernel (see
+ * mirx_set_tuning) and this entry point refuses it.
+ * (reference: torchvision _DenseLayer.conv2 followed, at the end of the block, by _Transition.norm / relu / pool, model.py:53-60)
+ */
+int mirx_conv3x3_direct_terms_nchw_pool(const void *y_terms, const void *w2, const float *oscale, int64_t n, int side, float *out,
+                                        int64_t out_batch_stride, const float *y_inv, float *out_range_or_null,
+                                        int64_t out_plane_stride, const float *pool_scale, const float *pool_shift,
+                                        float *pooled, int64_t pooled_batch_stride, void *stream);
+int mirx_conv3x3_small_launch(int64_t n, int side);
 
 /*
  * mirx_dense_layer_fused: the dense layer of the 14 x 14 and 7 x 7 maps (dense blocks 3 and 4) in ONE launch --
@@ -557,6 +573,11 @@ int mirx_bn_relu_nchw(const float *x, int64_t x_batch_stride, const float *scale
 int mirx_bn_relu_avgpool2(const float *x, int64_t x_batch_stride, const float *scale,
                           const float *shift, int64_t n, int c, int h, int w, float *y, int64_t x_plane_stride,
                           void *stream);    /* x_plane_stride: floats between channel planes of x (0 = h * w; else % 4 == 0) */
+/* ... the same with y = [n, >= c, h/2, w/2]: images `y_batch_stride` floats apart (the first c channels of a wider pooled map
+ * whose other channels mirx_conv3x3_direct_terms_nchw_pool writes) */
+int mirx_bn_relu_avgpool2_into(const float *x, int64_t x_batch_stride, const float *scale, const float *shift,
+                               int64_t n, int c, int h, int w, float *y, int64_t y_batch_stride, int64_t x_plane_stride,
+                               void *stream);
 
 /*
  * DenseNet stem: conv 7x7 stride 2 pad 3 (3 -> 64 channels) + folded BatchNorm + ReLU +

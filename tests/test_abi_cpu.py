@@ -20,7 +20,7 @@ def test_header_symbols_all_bound_and_exported():
     assert len(names) >= 15
     assert sorted(L.SYMBOLS) == names, "ctypes table and include/mirx.h disagree"
     lib = L.load()                      # raises if any symbol is missing from the .so
-    assert lib.mirx_version() == L.ABI_VERSION == 304
+    assert lib.mirx_version() == L.ABI_VERSION == 305
     for n in names:
         assert hasattr(lib, n)
 

@@ -485,6 +485,77 @@ def test_small_launch_conv3x3_is_bit_identical_to_the_strip_kernel(side, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side,n,ps_pad", [(56, 3, 0), (28, 5, 16), (14, 7, 0)])
+def test_pooled_twin_of_the_3x3_conv_is_bit_identical_to_the_pooling_pass(side, n, ps_pad):
+    """mirx_conv3x3_direct_terms_nchw_pool: the transition's norm + relu + avgpool2 of the 32 new channels, written by the 3x3
+    launch itself, against mirx_bn_relu_avgpool2 run on the stored outputs -- the same bits; the conv outputs and ranges are the
+    plain launch's; a poisoned image stays in its own rows; channels of the pooled map the launch does not own are untouched;
+    the entry point refuses launches that take the one-wave-per-block kernel."""
+    import ctypes
+    from mirx import _lib
+    from mirx.model import YTERMS_CHANNEL_ORDER, _conv3x3_weights_split2h, _split2h_weights
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(side * 7 + n)
+    cin, hw, hw2, ctot, c0 = 64, side * side, (side // 2) ** 2, 104, 64      # the launch owns channels 64..95 of a 104-channel block
+    ps = hw + ps_pad                                                        # padded channel planes of the block's buffer
+    buf = torch.randn(n, cin, hw, generator=g, device=dev)
+    buf *= (10.0 ** torch.randint(-2, 3, (n, 1, 1), generator=g, device=dev).float())
+    buf[1, 3, 5] = float("nan")                                             # image 1 is poisoned
+    w1 = torch.randn(128, cin, generator=g, device=dev) / cin ** 0.5
+    sc = torch.rand(cin, generator=g, device=dev) + 0.5
+    sh = torch.randn(cin, generator=g, device=dev) * 0.3
+    b1 = torch.randn(128, generator=g, device=dev) * 0.2
+    w3 = torch.randn(32, 128, 3, 3, generator=g, device=dev) * 0.05
+    tsc = torch.randn(ctot, generator=g, device=dev)                        # the transition's folded norm (either sign)
+    tsh = torch.randn(ctot, generator=g, device=dev) * 0.5
+    w2, osc = _split2h_weights(w1)
+    c3, c3osc = _conv3x3_weights_split2h(w3, YTERMS_CHANNEL_ORDER)
+    y = torch.empty((n, 128, hw), device=dev)
+    rng = buf.abs().amax(dim=(1, 2)).contiguous()
+    yinv = torch.zeros(n, device=dev)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                            # noqa: E731
+    off = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k)                # noqa: E731
+    _lib.check(lib.mirx_conv1x1_bn_relu_split2h_terms(vp(buf), cin * hw, cin, vp(sc), vp(sh), vp(w2), vp(osc), vp(b1), n, hw, vp(y),
+                                                      vp(rng), float(sc.abs().max()), float(sh.abs().max()),
+                                                      float(w1.abs().sum(dim=1).max()), float(b1.abs().max()), vp(yinv), 0, None), "terms")
+    try:
+        _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, 0), "set_tuning")       # strip kernel whatever the size
+        assert lib.mirx_conv3x3_small_launch(n, side) == 0
+        plain = torch.full((n, ctot, ps), -3.0, device=dev)
+        prng = torch.zeros(n, device=dev)
+        _lib.check(lib.mirx_conv3x3_direct_terms_nchw(vp(y), vp(c3), vp(c3osc), n, side, off(plain, c0 * ps), ctot * ps, vp(yinv),
+                                                      vp(prng), ps, None), "conv3x3_terms")
+        want = torch.full((n, ctot, hw2), -5.0, device=dev)
+        _lib.check(lib.mirx_bn_relu_avgpool2_into(off(plain, c0 * ps), ctot * ps, off(tsc, c0), off(tsh, c0), n, 32, side, side,
+                                                  off(want, c0 * hw2), ctot * hw2, ps, None), "pool_into")
+        out = torch.full((n, ctot, ps), -3.0, device=dev)
+        orng = torch.zeros(n, device=dev)
+        pooled = torch.full((n, ctot, hw2), -5.0, device=dev)
+        _lib.check(lib.mirx_conv3x3_direct_terms_nchw_pool(vp(y), vp(c3), vp(c3osc), n, side, off(out, c0 * ps), ctot * ps, vp(yinv),
+                                                           vp(orng), ps, off(tsc, c0), off(tsh, c0), off(pooled, c0 * hw2),
+                                                           ctot * hw2, None), "conv3x3_terms_pool")
+        torch.cuda.synchronize()
+        _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, 1 << 20), "set_tuning")  # ... and now the small kernel
+        assert lib.mirx_conv3x3_small_launch(n, side) == 1
+        assert lib.mirx_conv3x3_direct_terms_nchw_pool(vp(y), vp(c3), vp(c3osc), n, side, off(out, c0 * ps), ctot * ps, vp(yinv),
+                                                       vp(orng), ps, off(tsc, c0), off(tsh, c0), off(pooled, c0 * hw2),
+                                                       ctot * hw2, None) != 0
+        assert b"pooled twin" in lib.mirx_last_error()
+    finally:
+        _lib.check(lib.mirx_set_tuning(_lib.TUNE_CONV3X3_SMALL_MAX_WG, 96), "set_tuning")
+    assert torch.equal(out.view(torch.int32), plain.view(torch.int32)) and torch.equal(orng.view(torch.int32), prng.view(torch.int32))
+    assert torch.equal(pooled.view(torch.int32), want.view(torch.int32))
+    assert bool((pooled[:, :c0] == -5.0).all()) and bool((pooled[:, c0 + 32:] == -5.0).all())
+    ref = torch.nn.functional.avg_pool2d(torch.relu(out[:, c0:c0 + 32, :hw].double() * tsc[c0:c0 + 32].double()[None, :, None]
+                                                    + tsh[c0:c0 + 32].double()[None, :, None]).unflatten(2, (side, side)), 2).flatten(2)
+    for b in range(n):
+        if b == 1:
+            continue                                                        # (NaN conv outputs: relu's max drops them, as the pass does)
+        assert float((pooled[b, c0:c0 + 32].double() - ref[b]).abs().max()) < 1e-6 * float(ref[b].abs().max() + 1e-30), b
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,side,n,pad_in,pad_out", [(256, 28, 3, 16, 28), (512, 14, 2, 28, 0), (256, 56, 1, 0, 16)])
 def test_transition_kernels_with_padded_planes(c, side, n, pad_in, pad_out, conv1x1_kernel):
     """The two launches of a transition on buffers whose channel planes are padded (mirx.model._plane_stride):
