@@ -34,6 +34,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
 
+// Diagnostic builds (results wrong, timing only; -DMIRX_DIAG): bits of MIRX_ATT_EXP in k_attention_h2 -- 1 no softmax arithmetic,
+// 2 no tile staging after the first tile, 4 no P V MFMAs, 8 no Q K MFMAs, 16 no workgroup barrier in the K loop
+#ifndef MIRX_ATT_EXP
+#define MIRX_ATT_EXP 0
+#endif
 constexpr int DH = 64;                 // head dimension
 constexpr int KT = 32;                 // keys per tile
 constexpr int K_PLANE = KT * DH * 2;   // bytes of one term of the K tile (4 KiB)
@@ -200,8 +205,8 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
     store_tile(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int cur = kt & 1;
-        __syncthreads();                                   // tile kt visible; buffer cur ^ 1 free
-        load_tile(kt + 1 < ntiles ? kt + 1 : kt);          // branch-free: the last tile re-loads itself
+        if (!(MIRX_ATT_EXP & 16)) __syncthreads();         // tile kt visible; buffer cur ^ 1 free
+        if (!(MIRX_ATT_EXP & 2)) load_tile(kt + 1 < ntiles ? kt + 1 : kt);          // branch-free: the last tile re-loads itself
         __builtin_amdgcn_sched_barrier(0);
         const char *sb = sm + cur * BUF;
 
@@ -213,6 +218,7 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fk[ks]);
             const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fk[ks] + K_PLANE);
+            if (MIRX_ATT_EXP & 8) { sacc[ks] += (float)ah[0] + (float)al[1] + (float)qh[ks][2]; continue; }
             MIRX_MFMA3(sacc, ah, al, qh[ks], ql[ks])
         }
         // (the scores stay unscaled: s_inv, a power of two, goes into the exponent's multiply-add below -- the same bits)
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
         float psum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = exp2_raw(fmaf(sacc[r], s_inv, -m_new));
+            if (!(MIRX_ATT_EXP & 1)) sacc[r] = exp2_raw(fmaf(sacc[r], s_inv, -m_new));
             psum += sacc[r];
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
-        if (!__all(alpha == 1.0f)) {                       // wave-uniform: once the running maxima have settled there is nothing to rescale
+        if (!(MIRX_ATT_EXP & 1) && !__all(alpha == 1.0f)) {                       // wave-uniform: once the running maxima have settled there is nothing to rescale
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -262,10 +268,11 @@ __global__ __launch_bounds__(256, 3) void k_attention_h2(const float *__restrict
             for (int t = 0; t < 2; ++t) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8 *>(sb + fv[t][s] + V_PLANE);
+                if (MIRX_ATT_EXP & 4) { o[t][s] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3]; continue; }
                 MIRX_MFMA3(o[t], ah, al, bh, bl)
             }
         }
-        store_tile(cur ^ 1);
+        if (!(MIRX_ATT_EXP & 2)) store_tile(cur ^ 1);
     }
 
     // ---- normalise and store: register r of o[t] is channel 32 t + 8 (r >> 2) + (r & 3) + 4 half ------------------

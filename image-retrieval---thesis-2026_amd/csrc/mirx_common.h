@@ -17,7 +17,7 @@
      defined(MIRX_EXP_CYCLES) || defined(MIRX_C1H2_EXP_SKIP) || defined(MIRX_C1H2_EXP_SPLIT) ||                          \
      defined(MIRX_C1H2_EXP_ONE_MFMA) || defined(MIRX_C1H2_STAMPS) || defined(MIRX_LT2_EXP) || defined(MIRX_LH2_EXP) ||   \
      defined(MIRX_DF_EXP) || defined(MIRX_DF_STAMPS) || defined(MIRX_DW_STAMPS) || defined(MIRX_STEM_EXP) ||             \
-     defined(MIRX_W3_CYCLES) || defined(MIRX_D2P_WAVES) || defined(MIRX_STEM_PLAIN_ORDER))
+     defined(MIRX_W3_CYCLES) || defined(MIRX_D2P_WAVES) || defined(MIRX_STEM_PLAIN_ORDER) || defined(MIRX_ATT_EXP))
 #error "a MIRX diagnostic switch without -DMIRX_DIAG: these arms give wrong results or alter timing and must never reach libmirx.so"
 #endif
 
